@@ -1,0 +1,375 @@
+// cobyla_m0.h - Powell's COBYLA for the UNCONSTRAINED case (m = 0), written as an
+// ask/tell state machine in SPMD style so that the same source runs
+//   * on the host (one "thread"), and
+//   * inside a HIP workgroup (all threads of the block execute it together; loops are
+//     strided over the block, scalars are computed redundantly and stay bit-identical in
+//     every thread, shared vectors live in per-problem scratch memory).
+//
+// It replaces the reference's inner VQE loop
+//   scipy.optimize.minimize(cost, x0, method='COBYLA', options={'maxiter': 1000})
+// (reference environments/environment_qulacs_TN_notin_agent.py:478; scipy 1.15 defaults
+// rhobeg=1.0, rhoend=tol=1e-4, maxfun=maxiter), i.e. M.J.D. Powell's algorithm as
+// published ("A direct search optimization method that models the objective and constraint
+// functions by linear interpolation", 1994) and shipped by scipy <= 1.15 as cobyla2.f.  The
+// sequence of simplex operations, acceptance tests and the order of floating-point
+// accumulations follow that publication so that iterates agree with scipy's to rounding
+// (tests/test_cobyla.py pins this against recorded scipy 1.15.3 traces).
+//
+// With m = 0 the trust-region LP has the closed form dx = rho * a / |a| (a = minus the
+// model gradient); trstlp_m0() evaluates it with the same Givens accumulation the general
+// routine would perform on an identity Z matrix.
+//
+// Known quirk kept on purpose (it is observable through result.x in the reference): on
+// normal termination the returned point is the LAST trust-region trial point, not the best
+// vertex; on maxfun termination it is the best vertex.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define CBY_HD __host__ __device__
+#else
+#define CBY_HD
+#endif
+
+namespace cby {
+
+// Execution context for the host: one thread, no synchronisation.
+struct HostCtx {
+  static constexpr int tid = 0;
+  static constexpr int nth = 1;
+  CBY_HD void sync() const {}
+  CBY_HD int all_or(int v) const { return v; }
+};
+
+enum Status { RUNNING = 0, DONE_RHOEND = 1, DONE_MAXFUN = 2, DONE_ROUNDING = 3 };
+
+CBY_HD inline size_t scratch_doubles(int n) {
+  // x, sim, simi, datmat, a, vsig, veta, sigbar, dx, w
+  return (size_t)n + (size_t)(n + 1) * n + (size_t)n * n + (size_t)(n + 1) + 6 * (size_t)n + 2;
+}
+
+template <class Ctx, bool CHECK_INVERSE = false>
+struct CobylaM0 {
+  Ctx ctx;
+  int n, maxfun;
+  double rhoend;
+  // shared (per problem) arrays
+  double *x, *sim, *simi, *datmat, *a, *vsig, *veta, *sigbar, *dx, *w;
+  // scalars, identical in every thread
+  double rho, prerem, parsig, pareta, fbest_ret;
+  int nfvals, jdrop, ibrnch, iflag, ifull, status;
+
+  CBY_HD double &SIM(int i, int j) { return sim[(size_t)j * n + i]; }    // coordinate i of vertex j
+  CBY_HD double &SIMI(int j, int i) { return simi[(size_t)j * n + i]; }  // row j of the inverse
+
+  CBY_HD void bind(double *mem, int n_) {
+    n = n_;
+    x = mem; mem += n;
+    sim = mem; mem += (size_t)(n + 1) * n;
+    simi = mem; mem += (size_t)n * n;
+    datmat = mem; mem += n + 1;
+    a = mem; mem += n;
+    vsig = mem; mem += n;
+    veta = mem; mem += n;
+    sigbar = mem; mem += n;
+    dx = mem; mem += n;
+    w = mem;
+  }
+
+  // Begin a minimisation; x[] must already hold x0.  Returns 1 when f(x) is wanted.
+  CBY_HD int start(double rhobeg, double rhoend_, int maxfun_) {
+    rho = rhobeg; rhoend = rhoend_; maxfun = maxfun_;
+    nfvals = 0; ibrnch = 0; iflag = 0; ifull = 1; status = RUNNING; prerem = 0.0;
+    const double temp = 1.0 / rho;
+    for (int i = ctx.tid; i < n; i += ctx.nth) {
+      SIM(i, n) = x[i];
+      for (int j = 0; j < n; ++j) { SIM(i, j) = 0.0; SIMI(i, j) = 0.0; }
+      SIM(i, i) = rho;
+      SIMI(i, i) = temp;
+    }
+    jdrop = n;
+    ctx.sync();
+    return request_eval();
+  }
+
+  // Label 40: decide whether another evaluation may be made.
+  CBY_HD int request_eval() {
+    if (nfvals >= maxfun && nfvals > 0) { status = DONE_MAXFUN; return finish(false); }
+    ++nfvals;
+    return 1;
+  }
+
+  CBY_HD int finish(bool keep_x) {
+    if (!keep_x) {
+      for (int i = ctx.tid; i < n; i += ctx.nth) x[i] = SIM(i, n);
+      fbest_ret = datmat[n];
+    }
+    ctx.sync();
+    return 0;
+  }
+
+  // m = 0 trust-region step: dx = rho * a/|a| accumulated as the general routine does.
+  // Uses w[0..n) for the running direction and w[n..2n) is not needed.  Sets ifull.
+  CBY_HD void trstlp_m0() {
+    // Givens accumulation from k = n-1 down to 0 on Z = I (all threads, redundantly, for
+    // the scalar chain; the direction vector is built in parallel afterwards).
+    double tot = 0.0;
+    // alpha_k, beta_k are stored in vsig-independent scratch: reuse sigbar (alpha) and w (beta)
+    for (int k = n - 1; k >= 0; --k) {
+      double sp = a[k];
+      const double spabs = fabs(sp);
+      const double acca = spabs + 0.1 * fabs(sp);
+      const double accb = spabs + 0.2 * fabs(sp);
+      if (spabs >= acca || acca >= accb) sp = 0.0;
+      double al, be;
+      if (tot == 0.0) { tot = sp; al = 1.0; be = 0.0; }  // column k keeps e_k
+      else {
+        const double temp = sqrt(sp * sp + tot * tot);
+        al = sp / temp; be = tot / temp; tot = temp;
+      }
+      if (ctx.tid == 0) { sigbar[k] = al; w[k] = be; }
+    }
+    ctx.sync();
+    if (tot == 0.0) {  // no descent direction: short (zero) step
+      for (int i = ctx.tid; i < n; i += ctx.nth) dx[i] = 0.0;
+      ifull = 0;
+      ctx.sync();
+      return;
+    }
+    // z(:,0) after all rotations: z_i = alpha_i * beta_{i-1} * ... * beta_0 (rotation k
+    // multiplies the tail by beta_k, applied for k = i-1 down to 0).  Entries before the
+    // first non-zero sp (counting from the end) stay those of e_k, handled by al=1, be=0.
+    const double zdota = tot;
+    const double tinv = 1.0 / zdota;
+    for (int i = ctx.tid; i < n; i += ctx.nth) {
+      double z = sigbar[i];
+      for (int k = i - 1; k >= 0; --k) z = w[k] * z;
+      dx[i] = tinv * z;  // sdirn
+    }
+    ctx.sync();
+    double ss = 0.0;
+    for (int i = 0; i < n; ++i) ss += dx[i] * dx[i];
+    const double dd = rho * rho;
+    const double temp = sqrt(ss * dd);
+    const double step = dd / (temp + 0.0);
+    ctx.sync();
+    for (int i = ctx.tid; i < n; i += ctx.nth) dx[i] = 0.0 + step * dx[i];
+    ifull = 1;
+    ctx.sync();
+  }
+
+  // Report f(x) of the point handed out by the previous start()/tell().  Returns 1 when
+  // another evaluation (of the new x[]) is wanted, 0 when finished.
+  CBY_HD int tell(double f) {
+    int lbl;
+    if (ibrnch == 1) {
+      lbl = 440;
+    } else {
+      if (nfvals <= n + 1) {
+        const double fpole = (jdrop < n) ? datmat[n] : 0.0;
+        ctx.sync();
+        if (jdrop < n) {
+          if (fpole <= f) {
+            if (ctx.tid == 0) { x[jdrop] = SIM(jdrop, n); datmat[jdrop] = f; }
+          } else {
+            if (ctx.tid == 0) {
+              SIM(jdrop, n) = x[jdrop];
+              datmat[jdrop] = fpole;
+              datmat[n] = f;
+              for (int k = 0; k <= jdrop; ++k) {
+                SIM(jdrop, k) = -rho;
+                double temp = 0.0;
+                for (int i = k; i <= jdrop; ++i) temp -= SIMI(i, k);
+                SIMI(jdrop, k) = temp;
+              }
+            }
+          }
+        } else if (ctx.tid == 0) {
+          datmat[jdrop] = f;
+        }
+        ctx.sync();
+        if (nfvals <= n) {
+          jdrop = nfvals - 1;
+          if (ctx.tid == 0) x[jdrop] += rho;
+          ctx.sync();
+          return request_eval();
+        }
+      } else {
+        if (ctx.tid == 0) datmat[jdrop] = f;
+        ctx.sync();
+      }
+      ibrnch = 1;
+      lbl = 140;
+    }
+
+    double trured = 0.0;
+    for (;;) {
+      if (lbl == 140) {
+        // ---- identify the optimal vertex and move it to the pole position
+        double phimin = datmat[n];
+        int nbest = n;
+        for (int j = 0; j < n; ++j) {
+          const double t = datmat[j];
+          if (t < phimin) { nbest = j; phimin = t; }
+          // tie rule compares the (all-zero) constraint violations: never switches
+        }
+        ctx.sync();
+        if (nbest < n) {
+          if (ctx.tid == 0) { const double t = datmat[n]; datmat[n] = datmat[nbest]; datmat[nbest] = t; }
+          for (int i = ctx.tid; i < n; i += ctx.nth) {
+            const double temp = SIM(i, nbest);
+            SIM(i, nbest) = 0.0;
+            SIM(i, n) += temp;
+            double tempa = 0.0;
+            for (int k = 0; k < n; ++k) { SIM(i, k) -= temp; tempa -= SIMI(k, i); }
+            w[i] = tempa;  // becomes SIMI(nbest, i); deferred so column sums read old values
+          }
+          ctx.sync();
+          for (int i = ctx.tid; i < n; i += ctx.nth) SIMI(nbest, i) = w[i];
+          ctx.sync();
+        }
+        if (CHECK_INVERSE) {
+          int bad = 0;
+          for (int i = ctx.tid; i < n; i += ctx.nth)
+            for (int j = 0; j < n; ++j) {
+              double temp = (i == j) ? -1.0 : 0.0;
+              for (int k = 0; k < n; ++k) temp += SIMI(i, k) * SIM(k, j);
+              if (fabs(temp) > 0.1) bad = 1;
+            }
+          if (ctx.all_or(bad)) { status = DONE_ROUNDING; return finish(false); }
+        }
+        // ---- linear model: a = -grad
+        const double fp = datmat[n];
+        for (int i = ctx.tid; i < n; i += ctx.nth) {
+          double temp = 0.0;
+          for (int j = 0; j < n; ++j) temp += (datmat[j] - fp) * SIMI(j, i);
+          a[i] = -temp;
+        }
+        // ---- simplex acceptability
+        parsig = 0.25 * rho;
+        pareta = 2.1 * rho;
+        int flag_bad = 0;
+        for (int j = ctx.tid; j < n; j += ctx.nth) {
+          double wsig = 0.0, weta = 0.0;
+          for (int i = 0; i < n; ++i) { wsig += SIMI(j, i) * SIMI(j, i); weta += SIM(i, j) * SIM(i, j); }
+          const double vs = 1.0 / sqrt(wsig), ve = sqrt(weta);
+          vsig[j] = vs; veta[j] = ve;
+          if (vs < parsig || ve > pareta) flag_bad = 1;
+        }
+        iflag = ctx.all_or(flag_bad) ? 0 : 1;  // all_or synchronises
+        if (ibrnch == 1 || iflag == 1) { lbl = 370; continue; }
+        // ---- geometry step: replace the worst-placed vertex
+        int jd = -1;
+        double temp = pareta;
+        for (int j = 0; j < n; ++j) if (veta[j] > temp) { jd = j; temp = veta[j]; }
+        if (jd < 0) for (int j = 0; j < n; ++j) if (vsig[j] < temp) { jd = j; temp = vsig[j]; }
+        jdrop = jd;
+        temp = 0.5 * rho * vsig[jdrop];
+        double sum = 0.0;
+        for (int i = 0; i < n; ++i) sum += a[i] * (temp * SIMI(jdrop, i));
+        // dxsign = -1 iff parmu*(cvmaxp-cvmaxm) > 2*sum with parmu = 0
+        const double dxsign = (0.0 > sum + sum) ? -1.0 : 1.0;
+        ctx.sync();
+        for (int i = ctx.tid; i < n; i += ctx.nth) {
+          const double d = dxsign * (temp * SIMI(jdrop, i));
+          dx[i] = d;
+          SIM(i, jdrop) = d;
+        }
+        ctx.sync();
+        update_simi();
+        for (int j = ctx.tid; j < n; j += ctx.nth) x[j] = SIM(j, n) + dx[j];
+        ctx.sync();
+        return request_eval();  // ibrnch == 0: the value lands in datmat[jdrop]
+      }
+      if (lbl == 370) {
+        trstlp_m0();
+        if (ifull == 0) {
+          double t = 0.0;
+          for (int i = 0; i < n; ++i) t += dx[i] * dx[i];
+          if (t < 0.25 * rho * rho) { ibrnch = 1; lbl = 550; continue; }
+        }
+        double sum = 0.0;
+        for (int i = 0; i < n; ++i) sum -= a[i] * dx[i];
+        prerem = 0.0 - sum;  // parmu * prerec - sum with parmu = 0, prerec = 0
+        ctx.sync();
+        for (int i = ctx.tid; i < n; i += ctx.nth) x[i] = SIM(i, n) + dx[i];
+        ibrnch = 1;
+        ctx.sync();
+        return request_eval();
+      }
+      if (lbl == 440) {
+        const double vmold = datmat[n];
+        trured = vmold - f;
+        if (f == vmold) { prerem = 0.0; trured = 0.0; }
+        // ---- which vertex (if any) does x(*) replace
+        double ratio = (trured <= 0.0) ? 1.0 : 0.0;
+        for (int j = ctx.tid; j < n; j += ctx.nth) {
+          double t = 0.0;
+          for (int i = 0; i < n; ++i) t += SIMI(j, i) * dx[i];
+          t = fabs(t);
+          w[j] = t;
+          sigbar[j] = t * vsig[j];
+        }
+        ctx.sync();
+        int jd = -1;
+        for (int j = 0; j < n; ++j) if (w[j] > ratio) { jd = j; ratio = w[j]; }
+        ctx.sync();
+        for (int j = ctx.tid; j < n; j += ctx.nth) {
+          double t = -1.0;
+          if (sigbar[j] >= parsig || sigbar[j] >= vsig[j]) {
+            t = veta[j];
+            if (trured > 0.0) {
+              t = 0.0;
+              for (int i = 0; i < n; ++i) { const double d = dx[i] - SIM(i, j); t += d * d; }
+              t = sqrt(t);
+            }
+          }
+          w[j] = t;
+        }
+        ctx.sync();
+        double edgmax = 1.1 * rho;
+        int l = -1;
+        for (int j = 0; j < n; ++j) if (w[j] > edgmax) { l = j; edgmax = w[j]; }
+        if (l >= 0) jd = l;
+        if (jd < 0) { lbl = 550; continue; }
+        jdrop = jd;
+        ctx.sync();
+        for (int i = ctx.tid; i < n; i += ctx.nth) SIM(i, jdrop) = dx[i];
+        if (ctx.tid == 0) datmat[jdrop] = f;
+        ctx.sync();
+        update_simi();
+        if (trured > 0.0 && trured >= 0.1 * prerem) { lbl = 140; continue; }
+        lbl = 550;
+        continue;
+      }
+      // lbl == 550
+      if (iflag == 0) { ibrnch = 0; lbl = 140; continue; }
+      if (rho > rhoend) {
+        rho = 0.5 * rho;
+        if (rho <= 1.5 * rhoend) rho = rhoend;
+        lbl = 140;
+        continue;
+      }
+      status = DONE_RHOEND;
+      return finish(ifull == 1);
+    }
+  }
+
+  // Rank-one update of SIMI after vertex jdrop was replaced by pole + dx.
+  CBY_HD void update_simi() {
+    double temp = 0.0;
+    for (int i = 0; i < n; ++i) temp += SIMI(jdrop, i) * dx[i];
+    ctx.sync();
+    for (int i = ctx.tid; i < n; i += ctx.nth) SIMI(jdrop, i) /= temp;
+    ctx.sync();
+    for (int j = ctx.tid; j < n; j += ctx.nth) {
+      if (j == jdrop) continue;
+      double t = 0.0;
+      for (int i = 0; i < n; ++i) t += SIMI(j, i) * dx[i];
+      for (int i = 0; i < n; ++i) SIMI(j, i) -= t * SIMI(jdrop, i);
+    }
+    ctx.sync();
+  }
+};
+
+}  // namespace cby
