@@ -1,0 +1,134 @@
+/* vqe_hip.h - C ABI of the MI355X VQE environment-step engine (libvqe_hip.so).
+ *
+ * The reference (Aqasch/TensorRL-QAS) has no FFI: its hot path is Python calling the
+ * third-party qulacs / numpy / scipy packages.  Each entry point below names the reference
+ * interface it replaces (paths relative to the reference checkout).  Plain C types only;
+ * every function returns 0 on success or a negative VQE_E* code and never throws or
+ * aborts across the ABI; vqe_last_error() returns the message of the last failure.
+ *
+ * Conventions (identical to the reference's simulator, qulacs):
+ *   - qubit k is bit k of the basis-state index (little-endian);
+ *   - amplitudes are complex128, interleaved (re, im);
+ *   - rotations are exp(+i*theta/2*P)  (qulacs add_parametric_R{X,Y,Z}_gate);
+ *   - Pauli terms are (xmask, zmask, coeff): bit k of xmask set iff the factor on qubit k
+ *     is X or Y, bit k of zmask set iff it is Z or Y; the i^{#Y} phase is applied by the
+ *     callee.
+ * A handle is not thread-safe; distinct handles are independent.  All work of a handle is
+ * issued on one HIP stream (vqe_set_stream); calls that return results in host memory
+ * block until those results are ready.
+ */
+#ifndef VQE_HIP_H
+#define VQE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vqe_handle vqe_t;
+typedef struct vqe_cobyla vqe_cobyla_t;
+
+enum {
+  VQE_OK = 0,
+  VQE_EINVAL = -22,   /* bad argument */
+  VQE_ENOMEM = -12,   /* host or device allocation failed */
+  VQE_ENODEV = -19,   /* no usable HIP device */
+  VQE_EHIP = -5,      /* a HIP runtime call failed */
+  VQE_ESTATE = -1     /* call sequence error (e.g. no circuit / Hamiltonian set) */
+};
+
+/* gate kinds of a circuit description (order = reference construct_ansatz order,
+ * environments/VQAs/VQE_qulacs_TN_notin_RL.py:13-45; noise kinds:
+ * VQE_qulacs_TN_notin_RL_noise.py:26-28,40-50) */
+enum {
+  VQE_GATE_CNOT = 0,   /* q0 = control, q1 = target                       */
+  VQE_GATE_RX = 1,     /* q0 = qubit, param_idx = index into theta        */
+  VQE_GATE_RY = 2,
+  VQE_GATE_RZ = 3,
+  VQE_GATE_DEPOL1 = 4, /* DepolarizingNoise(q0, p1)                       */
+  VQE_GATE_DEPOL2 = 5  /* TwoQubitDepolarizingNoise(q0, q1, p2)           */
+};
+
+/* ---- lifetime ------------------------------------------------------------------------
+ * replaces: qulacs.QuantumState(n) / ParametricQuantumCircuit(n) construction,
+ * environments/VQAs/VQE_qulacs_TN_notin_RL.py:10,82 */
+int vqe_create(int n_qubits, int device_id, vqe_t** out);
+void vqe_destroy(vqe_t* h);
+const char* vqe_last_error(const vqe_t* h); /* h may be NULL: last error of vqe_create */
+int vqe_set_stream(vqe_t* h, void* hip_stream); /* NULL: the handle's own stream */
+int vqe_sync(vqe_t* h);
+/* device facts for the caller's roofline arithmetic: [0]=CU count, [1]=LDS bytes/CU,
+ * [2]=workgroups resident per CU for the last LDS-path launch, [3]=1 if the LDS-resident
+ * path serves this n_qubits else 0 */
+int vqe_device_info(vqe_t* h, int64_t info[4]);
+
+/* ---- problem definition --------------------------------------------------------------
+ * replaces: state.load(TN_state)            VQE_qulacs_TN_notin_RL.py:83
+ *           (NULL = |0...0>, the VQE_qulacs.py:81 path) */
+int vqe_set_init_state(vqe_t* h, const double* amps_re_im /* 2 * 2^n, or NULL */);
+/* replaces: the dense operator handed to get_exp_val (VQE_qulacs_TN_notin_RL.py:80,86;
+ * built at environment_qulacs_TN_notin_agent.py:126-131,162) by its Pauli-sum form */
+int vqe_set_hamiltonian_pauli(vqe_t* h, int n_terms, const uint64_t* xmask,
+                              const uint64_t* zmask, const double* coeff);
+/* Evaluate only the X-mask groups owned by `rank` of `world` (Pauli-term sharding; the
+ * caller sums the partial energies of all ranks, e.g. one RCCL all-reduce). */
+int vqe_set_term_shard(vqe_t* h, int rank, int world);
+/* Stochastic Pauli noise (qulacs DepolarizingNoise / TwoQubitDepolarizingNoise
+ * semantics: each non-identity Pauli with probability p/3 resp. p/15, one trajectory per
+ * evaluation).  The draw for (stream, evaluation, gate) is a pure function of `seed`. */
+int vqe_set_noise(vqe_t* h, double p1, double p2, uint64_t seed);
+
+/* ---- one circuit ---------------------------------------------------------------------
+ * replaces: Parametric_Circuit.construct_ansatz product (the qulacs circuit handle),
+ * VQE_qulacs_TN_notin_RL.py:13-45 */
+int vqe_set_circuit(vqe_t* h, int n_gates, const int32_t* kind, const int32_t* q0,
+                    const int32_t* q1, const int32_t* param_idx, int n_params);
+/* replaces: get_energy_qulacs / get_exp_val, VQE_qulacs_TN_notin_RL.py:48-87 */
+int vqe_energy(vqe_t* h, const double* theta, double* energy);
+int vqe_energy_batch(vqe_t* h, int batch, const double* theta /* batch x n_params */,
+                     double* energy /* batch */);
+/* replaces: circuit.update_quantum_state(state); state.get_vector()  (:84-85) */
+int vqe_get_state(vqe_t* h, const double* theta, double* amps_re_im /* 2 * 2^n */);
+/* replaces: scipy.optimize.minimize(cost, x0, method='COBYLA', options={'maxiter': m})
+ * at environment_qulacs_TN_notin_agent.py:478 (scipy 1.15: rhobeg=1.0, rhoend=1e-4,
+ * maxfun=m).  The whole loop (simplex algebra + evaluations) runs on the device. */
+int vqe_minimize_cobyla(vqe_t* h, const double* x0, double rhobeg, double rhoend,
+                        int maxfun, double* x, double* f, int32_t* nfev);
+
+/* ---- batches of independent circuits (one per parallel environment / RL seed) ---------
+ * Circuits are concatenated; circuit b owns gates [gate_off[b], gate_off[b+1]) and
+ * parameters [par_off[b], par_off[b+1]); param_idx is local to the circuit.
+ * vqe_batch_load copies the description (and x0 / theta) into device memory; the
+ * *_run calls only launch device work on resident data; vqe_batch_fetch copies results
+ * back.  replaces: B independent CircuitEnv.scipy_optim / get_energy calls
+ * (environment_qulacs_TN_notin_agent.py:442-482). */
+int vqe_batch_load(vqe_t* h, int batch, const int64_t* gate_off, const int32_t* kind,
+                   const int32_t* q0, const int32_t* q1, const int32_t* param_idx,
+                   const int64_t* par_off, const double* theta0);
+int vqe_batch_run_energy(vqe_t* h);
+int vqe_batch_run_minimize(vqe_t* h, double rhobeg, double rhoend, int maxfun);
+int vqe_batch_fetch(vqe_t* h, double* x /* sum of n_params, may be NULL */,
+                    double* f /* batch */, int32_t* nfev /* batch, may be NULL */);
+/* device pointer to the batch's f / energy array (float64[batch]) for on-device
+ * reductions by the caller (e.g. torch.distributed all_reduce over RCCL) */
+int vqe_batch_energy_devptr(vqe_t* h, void** dev_ptr);
+/* kernel time of the last *_run call measured with HIP events on the handle's stream */
+int vqe_last_kernel_ms(vqe_t* h, float* ms);
+
+/* ---- host-side COBYLA (ask/tell) -------------------------------------------------------
+ * Same algorithm as the device loop; used when every evaluation needs a collective
+ * (Pauli-term sharding across GPUs) or by a caller with its own cost function.
+ * replaces: scipy.optimize.minimize(..., method='COBYLA') as above. */
+int vqe_cobyla_create(int n, const double* x0, double rhobeg, double rhoend, int maxfun,
+                      vqe_cobyla_t** out);
+/* returns 1 and fills x[n] when f(x) is wanted, 0 when finished, <0 on error */
+int vqe_cobyla_ask(vqe_cobyla_t* c, double* x);
+int vqe_cobyla_tell(vqe_cobyla_t* c, double f);
+int vqe_cobyla_result(vqe_cobyla_t* c, double* x, double* f, int32_t* nfev, int32_t* status);
+void vqe_cobyla_destroy(vqe_cobyla_t* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQE_HIP_H */

@@ -1,0 +1,68 @@
+"""ctypes binding of libvqe_hip.so (include/vqe_hip.h).  No fallback: if the shared library
+is missing or no HIP device is present the engine raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqe_hip.so")
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u64p = C.POINTER(C.c_uint64)
+c_f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/vqe_hip.h one to one
+SIGNATURES = {
+    "vqe_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(vp)]),
+    "vqe_destroy": (None, [vp]),
+    "vqe_last_error": (C.c_char_p, [vp]),
+    "vqe_set_stream": (C.c_int, [vp, vp]),
+    "vqe_sync": (C.c_int, [vp]),
+    "vqe_device_info": (C.c_int, [vp, c_i64p]),
+    "vqe_set_init_state": (C.c_int, [vp, c_f64p]),
+    "vqe_set_hamiltonian_pauli": (C.c_int, [vp, C.c_int, c_u64p, c_u64p, c_f64p]),
+    "vqe_set_term_shard": (C.c_int, [vp, C.c_int, C.c_int]),
+    "vqe_set_noise": (C.c_int, [vp, C.c_double, C.c_double, C.c_uint64]),
+    "vqe_set_circuit": (C.c_int, [vp, C.c_int, c_i32p, c_i32p, c_i32p, c_i32p, C.c_int]),
+    "vqe_energy": (C.c_int, [vp, c_f64p, c_f64p]),
+    "vqe_energy_batch": (C.c_int, [vp, C.c_int, c_f64p, c_f64p]),
+    "vqe_get_state": (C.c_int, [vp, c_f64p, c_f64p]),
+    "vqe_minimize_cobyla": (C.c_int, [vp, c_f64p, C.c_double, C.c_double, C.c_int, c_f64p, c_f64p, c_i32p]),
+    "vqe_batch_load": (C.c_int, [vp, C.c_int, c_i64p, c_i32p, c_i32p, c_i32p, c_i32p, c_i64p, c_f64p]),
+    "vqe_batch_run_energy": (C.c_int, [vp]),
+    "vqe_batch_run_minimize": (C.c_int, [vp, C.c_double, C.c_double, C.c_int]),
+    "vqe_batch_fetch": (C.c_int, [vp, c_f64p, c_f64p, c_i32p]),
+    "vqe_batch_energy_devptr": (C.c_int, [vp, C.POINTER(vp)]),
+    "vqe_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "vqe_cobyla_create": (C.c_int, [C.c_int, c_f64p, C.c_double, C.c_double, C.c_int, C.POINTER(vp)]),
+    "vqe_cobyla_ask": (C.c_int, [vp, c_f64p]),
+    "vqe_cobyla_tell": (C.c_int, [vp, C.c_double]),
+    "vqe_cobyla_result": (C.c_int, [vp, c_f64p, c_f64p, c_i32p, c_i32p]),
+    "vqe_cobyla_destroy": (None, [vp]),
+}
+
+_lib = None
+
+
+class VQEError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libvqe_hip.so once; raises VQEError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VQEError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

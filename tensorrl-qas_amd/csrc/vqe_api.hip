@@ -1,0 +1,685 @@
+// vqe_api.hip - host side of libvqe_hip.so: handle management, Hamiltonian tables, batch
+// upload and kernel dispatch behind the C ABI of include/vqe_hip.h.
+#include "../../include/vqe_hip.h"
+#include "vqe_device.h"
+#include "vqe_stream.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace vqe;
+
+namespace {
+
+std::string g_create_error;
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = n + n / 4 + 16;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+};
+
+}  // namespace
+
+struct vqe_handle {
+  int n = 0, dev = 0;
+  bool lds_path = true;
+  int cu_count = 0, lds_per_cu = 0, last_wg_per_cu = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  std::string err;
+
+  DevBuf<double2> init;
+  // Hamiltonian (host copy, grouped by X mask)
+  std::vector<uint32_t> gx_all;
+  std::vector<std::vector<int>> group_terms;
+  std::vector<uint64_t> hx, hz;
+  std::vector<double> hcr, hci;
+  int shard_rank = 0, shard_world = 1;
+  bool ham_set = false;
+  DevBuf<uint32_t> d_gx, d_term_z;
+  DevBuf<int64_t> d_tab_r, d_tab_i;
+  DevBuf<double> d_tables, d_term_cr, d_term_ci;
+  DevBuf<int32_t> d_term_off;
+  HamDev ham{};
+  NoiseCfg noise{0.0, 0.0, 0ull, 0ull};
+
+  // single circuit
+  std::vector<GateRec> circ;
+  int circ_params = -1;
+
+  // resident batch
+  int batch = 0;
+  int64_t total_params = 0;
+  int max_ops = 0, max_params = 0;
+  std::vector<int64_t> h_par_begin;
+  std::vector<int32_t> h_par_count;
+  DevBuf<GateRec> d_gates;
+  DevBuf<int64_t> d_gate_begin, d_par_begin, d_scratch_begin;
+  DevBuf<int32_t> d_gate_count, d_par_count, d_nfev;
+  DevBuf<double> d_theta, d_f, d_scratch;
+  DevBuf<double2> d_state;
+  StreamWork sw;  // streaming-path work buffers
+};
+
+namespace {
+
+int fail(vqe_t* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+#define HIP_TRY(h, expr)                                                               \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return fail(h, _e == hipErrorOutOfMemory ? VQE_ENOMEM : VQE_EHIP,                \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+  } while (0)
+
+template <class T>
+int upload(vqe_t* h, DevBuf<T>& b, const T* src, size_t n) {
+  HIP_TRY(h, b.reserve(n ? n : 1));
+  if (n) HIP_TRY(h, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  return VQE_OK;
+}
+
+// Build (or rebuild after re-sharding) the device Hamiltonian.
+int build_hamiltonian(vqe_t* h) {
+  const int n = h->n;
+  const size_t dim = (size_t)1 << n;
+  // greedy bin packing of X-mask groups over ranks by cost (terms for the streaming path,
+  // table length for the LDS path); deterministic.
+  std::vector<int> order(h->gx_all.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  auto cost = [&](int g) -> double {
+    return h->lds_path ? (h->gx_all[g] == 0 ? 2.0 : 1.0) : 1.0 + 0.25 * h->group_terms[g].size();
+  };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+  std::vector<double> load(h->shard_world, 0.0);
+  std::vector<int> mine;
+  for (int g : order) {
+    int best = 0;
+    for (int r = 1; r < h->shard_world; ++r) if (load[r] < load[best]) best = r;
+    load[best] += cost(g);
+    if (best == h->shard_rank) mine.push_back(g);
+  }
+  std::sort(mine.begin(), mine.end());
+
+  std::vector<uint32_t> gx;
+  std::vector<int64_t> tab_r, tab_i;
+  std::vector<double> tables;
+  std::vector<int32_t> term_off{0};
+  std::vector<uint32_t> term_z;
+  std::vector<double> term_cr, term_ci;
+  for (int g : mine) {
+    const uint32_t x = h->gx_all[g];
+    gx.push_back(x);
+    bool has_im = false;
+    for (int k : h->group_terms[g]) {
+      term_z.push_back((uint32_t)h->hz[k]);
+      term_cr.push_back(h->hcr[k]);
+      term_ci.push_back(h->hci[k]);
+      if (h->hci[k] != 0.0) has_im = true;
+    }
+    term_off.push_back((int32_t)term_z.size());
+    if (h->lds_path) {
+      const size_t len = x == 0 ? dim : dim / 2;
+      const int hb = x == 0 ? 0 : 31 - __builtin_clz(x);
+      tab_r.push_back((int64_t)tables.size());
+      tables.resize(tables.size() + len, 0.0);
+      double* tr = tables.data() + tab_r.back();
+      double* ti = nullptr;
+      if (has_im) {
+        tab_i.push_back((int64_t)tables.size());
+        tables.resize(tables.size() + len, 0.0);
+        tr = tables.data() + tab_r.back();
+        ti = tables.data() + tab_i.back();
+      } else {
+        tab_i.push_back(-1);
+      }
+      for (int k : h->group_terms[g]) {
+        const uint32_t z = (uint32_t)h->hz[k];
+        for (size_t q = 0; q < len; ++q) {
+          const uint32_t p = x == 0 ? (uint32_t)q
+                                    : (uint32_t)(((q >> hb) << (hb + 1)) | (q & (((size_t)1 << hb) - 1)));
+          const double s = (__builtin_popcount(p & z) & 1) ? -1.0 : 1.0;
+          tr[q] += s * h->hcr[k];
+          if (ti) ti[q] += s * h->hci[k];
+        }
+      }
+    } else {
+      tab_r.push_back(0);
+      tab_i.push_back(has_im ? 0 : -1);
+    }
+  }
+  int rc;
+  if ((rc = upload(h, h->d_gx, gx.data(), gx.size()))) return rc;
+  if ((rc = upload(h, h->d_tab_r, tab_r.data(), tab_r.size()))) return rc;
+  if ((rc = upload(h, h->d_tab_i, tab_i.data(), tab_i.size()))) return rc;
+  if ((rc = upload(h, h->d_tables, tables.data(), tables.size()))) return rc;
+  if ((rc = upload(h, h->d_term_off, term_off.data(), term_off.size()))) return rc;
+  if ((rc = upload(h, h->d_term_z, term_z.data(), term_z.size()))) return rc;
+  if ((rc = upload(h, h->d_term_cr, term_cr.data(), term_cr.size()))) return rc;
+  if ((rc = upload(h, h->d_term_ci, term_ci.data(), term_ci.size()))) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // host vectors go out of scope
+  h->ham.n_groups = (int)gx.size();
+  h->ham.n_terms = (int)term_z.size();
+  h->ham.gx = h->d_gx.p;
+  h->ham.tab_r = h->d_tab_r.p;
+  h->ham.tab_i = h->d_tab_i.p;
+  h->ham.tables = h->d_tables.p;
+  h->ham.term_off = h->d_term_off.p;
+  h->ham.term_z = h->d_term_z.p;
+  h->ham.term_cr = h->d_term_cr.p;
+  h->ham.term_ci = h->d_term_ci.p;
+  return VQE_OK;
+}
+
+int check_gates(vqe_t* h, int64_t n_gates, const int32_t* kind, const int32_t* q0,
+                const int32_t* q1, const int32_t* pidx, int n_params) {
+  for (int64_t i = 0; i < n_gates; ++i) {
+    const int k = kind[i];
+    if (k < 0 || k > VQE_GATE_DEPOL2) return fail(h, VQE_EINVAL, "unknown gate kind");
+    if (q0[i] < 0 || q0[i] >= h->n) return fail(h, VQE_EINVAL, "gate qubit out of range");
+    if (k == VQE_GATE_CNOT || k == VQE_GATE_DEPOL2) {
+      if (q1[i] < 0 || q1[i] >= h->n || q1[i] == q0[i])
+        return fail(h, VQE_EINVAL, "two-qubit gate needs two distinct qubits in range");
+    }
+    if (k >= VQE_GATE_RX && k <= VQE_GATE_RZ) {
+      if (pidx[i] < 0 || pidx[i] >= n_params)
+        return fail(h, VQE_EINVAL, "rotation parameter index out of range");
+    }
+  }
+  return VQE_OK;
+}
+
+template <int N>
+int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
+  const size_t lds = lds_bytes(N, A.max_ops, A.max_params);
+  if (lds > (size_t)h->lds_per_cu)
+    return fail(h, VQE_EINVAL, "circuit too large for the LDS-resident path (gates + parameters)");
+  const void* fn = which == 0 ? (const void*)k_lds_energy<N>
+                   : which == 1 ? (const void*)k_lds_minimize<N>
+                                : (const void*)k_lds_state<N>;
+  HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  h->last_wg_per_cu = std::max(1, std::min(8, (int)(h->lds_per_cu / lds)));
+  HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  const dim3 grid(which == 2 ? 1 : A.batch), block(kThreads);
+  if (which == 0) hipLaunchKernelGGL(k_lds_energy<N>, grid, block, lds, h->stream, A);
+  else if (which == 1) hipLaunchKernelGGL(k_lds_minimize<N>, grid, block, lds, h->stream, A);
+  else hipLaunchKernelGGL(k_lds_state<N>, grid, block, lds, h->stream, A);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+  return VQE_OK;
+}
+
+int dispatch_lds(vqe_t* h, int which, const BatchArgs& A) {
+  switch (h->n) {
+#define C(N) case N: return launch_lds<N>(h, which, A);
+    C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13)
+#undef C
+  }
+  return fail(h, VQE_EINVAL, "n_qubits outside the LDS-resident range");
+}
+
+BatchArgs make_args(vqe_t* h) {
+  BatchArgs A{};
+  A.n = h->n;
+  A.batch = h->batch;
+  A.gates = h->d_gates.p;
+  A.gate_begin = h->d_gate_begin.p;
+  A.gate_count = h->d_gate_count.p;
+  A.par_begin = h->d_par_begin.p;
+  A.par_count = h->d_par_count.p;
+  A.theta = h->d_theta.p;
+  A.fout = h->d_f.p;
+  A.nfev = h->d_nfev.p;
+  A.scratch = h->d_scratch.p;
+  A.scratch_begin = h->d_scratch_begin.p;
+  A.init = h->init.p;
+  A.ham = h->ham;
+  A.noise = h->noise;
+  A.max_ops = h->max_ops;
+  A.max_params = h->max_params;
+  A.state_out = h->d_state.p;
+  return A;
+}
+
+// Load a batch given begin/count arrays (circuits may alias the same gate range).
+int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
+               const std::vector<int64_t>& gbeg, const std::vector<int32_t>& gcnt,
+               const std::vector<int64_t>& pbeg, const std::vector<int32_t>& pcnt,
+               const double* theta0, int64_t total_params) {
+  int rc;
+  std::vector<int64_t> sbeg(batch);
+  int64_t stot = 0;
+  int max_ops = 1, max_par = 1;
+  for (int b = 0; b < batch; ++b) {
+    sbeg[b] = stot;
+    stot += (int64_t)cby::scratch_doubles(pcnt[b]);
+    stot = (stot + 1) & ~(int64_t)1;  // keep 16-byte alignment
+    max_par = std::max(max_par, (int)pcnt[b]);
+    int ops = 0;
+    for (int64_t i = gbeg[b]; i < gbeg[b] + gcnt[b]; ++i) {
+      const int k = gates[i].kind;
+      ops += (k == G_CNOT) ? 0 : (k == G_DEPOL2 ? 2 : 1);
+    }
+    max_ops = std::max(max_ops, ops);
+  }
+  if ((rc = upload(h, h->d_gates, gates.data(), gates.size()))) return rc;
+  if ((rc = upload(h, h->d_gate_begin, gbeg.data(), gbeg.size()))) return rc;
+  if ((rc = upload(h, h->d_gate_count, gcnt.data(), gcnt.size()))) return rc;
+  if ((rc = upload(h, h->d_par_begin, pbeg.data(), pbeg.size()))) return rc;
+  if ((rc = upload(h, h->d_par_count, pcnt.data(), pcnt.size()))) return rc;
+  if ((rc = upload(h, h->d_scratch_begin, sbeg.data(), sbeg.size()))) return rc;
+  if ((rc = upload(h, h->d_theta, theta0, (size_t)total_params))) return rc;
+  HIP_TRY(h, h->d_scratch.reserve((size_t)stot + 2));
+  HIP_TRY(h, h->d_f.reserve(batch));
+  HIP_TRY(h, h->d_nfev.reserve(batch));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->batch = batch;
+  h->total_params = total_params;
+  h->max_ops = (max_ops + 3) & ~3;
+  h->max_params = (max_par + 3) & ~3;
+  h->h_par_begin = pbeg;
+  h->h_par_count = pcnt;
+  return VQE_OK;
+}
+
+int load_single(vqe_t* h, int batch, const double* theta) {
+  if (h->circ_params < 0) return fail(h, VQE_ESTATE, "vqe_set_circuit has not been called");
+  const int P = h->circ_params;
+  std::vector<int64_t> gbeg(batch, 0), pbeg(batch);
+  std::vector<int32_t> gcnt(batch, (int32_t)h->circ.size()), pcnt(batch, P);
+  for (int b = 0; b < batch; ++b) pbeg[b] = (int64_t)b * P;
+  return load_batch(h, batch, h->circ, gbeg, gcnt, pbeg, pcnt, theta, (int64_t)batch * P);
+}
+
+int ready(vqe_t* h) {
+  if (!h) return VQE_EINVAL;
+  if (!h->ham_set) return fail(h, VQE_ESTATE, "vqe_set_hamiltonian_pauli has not been called");
+  if (h->batch <= 0) return fail(h, VQE_ESTATE, "no circuits loaded");
+  return VQE_OK;
+}
+
+// Streaming path (n >= 14): kernels per op; the COBYLA loop is host driven, all streams in
+// lock-step (one batched evaluation per iteration).
+int stream_run(vqe_t* h, int which, BatchArgs& A) {
+  HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  int rc = 0;
+  if (which == 0) {
+    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base, true, h->err);
+  } else if (which == 2) {
+    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base, false, h->err);
+    if (!rc) {
+      const size_t dim = (size_t)1 << h->n;
+      hipLaunchKernelGGL(k_s_state_out, dim3((unsigned)(dim / kThreads)), dim3(kThreads), 0, h->stream, A,
+                         h->sw.states, h->sw.masks, h->sw.meta);
+      HIP_TRY(h, hipGetLastError());
+    }
+  } else {
+    const int B = h->batch;
+    std::vector<double> x((size_t)h->total_params), f(B, 0.0), flast(B, 0.0);
+    if (h->total_params)
+      HIP_TRY(h, hipMemcpyAsync(x.data(), h->d_theta.p, x.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<vqe_cobyla_t*> cob(B, nullptr);
+    struct Guard { std::vector<vqe_cobyla_t*>& v; ~Guard() { for (auto* c : v) vqe_cobyla_destroy(c); } } guard{cob};
+    for (int b = 0; b < B; ++b)
+      if (vqe_cobyla_create(h->h_par_count[b], x.data() + h->h_par_begin[b], A.rhobeg, A.rhoend, A.maxfun, &cob[b]))
+        return fail(h, VQE_ENOMEM, "host COBYLA allocation failed");
+    uint64_t it = 0;
+    for (;;) {
+      int active = 0;
+      for (int b = 0; b < B; ++b) active += vqe_cobyla_ask(cob[b], x.data() + h->h_par_begin[b]) == 1;
+      if (!active) break;
+      if (h->total_params)
+        HIP_TRY(h, hipMemcpyAsync(h->d_theta.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
+      rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base + (++it), true, h->err);
+      if (rc) return rc;
+      HIP_TRY(h, hipMemcpyAsync(f.data(), h->d_f.p, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      for (int b = 0; b < B; ++b)
+        if (vqe_cobyla_ask(cob[b], nullptr) == 1) vqe_cobyla_tell(cob[b], f[b]);
+    }
+    std::vector<int32_t> nfev(B);
+    for (int b = 0; b < B; ++b) vqe_cobyla_result(cob[b], x.data() + h->h_par_begin[b], &f[b], &nfev[b], nullptr);
+    if (h->total_params)
+      HIP_TRY(h, hipMemcpyAsync(h->d_theta.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_f.p, f.data(), (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_nfev.p, nfev.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  if (rc) return rc;
+  HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+  return VQE_OK;
+}
+
+int run(vqe_t* h, int which, double rhobeg, double rhoend, int maxfun) {
+  HIP_TRY(h, hipSetDevice(h->dev));
+  BatchArgs A = make_args(h);
+  A.rhobeg = rhobeg; A.rhoend = rhoend; A.maxfun = maxfun;
+  int rc;
+  if (which == 1 && h->shard_world > 1)
+    return fail(h, VQE_ESTATE, "term-sharded handles hold partial energies: drive COBYLA with "
+                               "vqe_cobyla_ask/tell and sum the partial energies of all ranks");
+  if (h->lds_path) rc = dispatch_lds(h, which, A);
+  else rc = stream_run(h, which, A);
+  if (rc) return rc;
+  // every evaluation of a stochastic run consumes fresh trajectory numbers
+  h->noise.eval_base += (which == 1 ? (uint64_t)maxfun + 1 : 1);
+  return VQE_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+int vqe_create(int n_qubits, int device_id, vqe_t** out) {
+  if (!out) return fail(nullptr, VQE_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (n_qubits < 1 || n_qubits > 30) return fail(nullptr, VQE_EINVAL, "n_qubits must be in [1, 30]");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, VQE_ENODEV, "no HIP device available (the VQE engine has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, VQE_EINVAL, "device_id out of range");
+  vqe_t* h = new (std::nothrow) vqe_t;
+  if (!h) return fail(nullptr, VQE_ENOMEM, "out of host memory");
+  h->n = n_qubits;
+  h->dev = device_id;
+  h->lds_path = n_qubits <= 13;
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    delete h;
+    return fail(nullptr, VQE_EHIP, "HIP device initialisation failed");
+  }
+  h->stream = h->own_stream;
+  h->cu_count = prop.multiProcessorCount;
+  h->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (h->lds_per_cu <= 0) h->lds_per_cu = 65536;
+  *out = h;
+  int rc = vqe_set_init_state(h, nullptr);
+  if (rc) { g_create_error = h->err; vqe_destroy(h); *out = nullptr; return rc; }
+  return VQE_OK;
+}
+
+void vqe_destroy(vqe_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->dev);
+  (void)hipStreamSynchronize(h->stream);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+const char* vqe_last_error(const vqe_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int vqe_set_stream(vqe_t* h, void* s) {
+  if (!h) return VQE_EINVAL;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return VQE_OK;
+}
+
+int vqe_sync(vqe_t* h) {
+  if (!h) return VQE_EINVAL;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VQE_OK;
+}
+
+int vqe_device_info(vqe_t* h, int64_t info[4]) {
+  if (!h || !info) return VQE_EINVAL;
+  info[0] = h->cu_count; info[1] = h->lds_per_cu; info[2] = h->last_wg_per_cu; info[3] = h->lds_path;
+  return VQE_OK;
+}
+
+int vqe_set_init_state(vqe_t* h, const double* amps) {
+  if (!h) return VQE_EINVAL;
+  HIP_TRY(h, hipSetDevice(h->dev));
+  const size_t dim = (size_t)1 << h->n;
+  HIP_TRY(h, h->init.reserve(dim));
+  if (amps) {
+    HIP_TRY(h, hipMemcpyAsync(h->init.p, amps, dim * 16, hipMemcpyHostToDevice, h->stream));
+  } else {
+    const double one[2] = {1.0, 0.0};
+    HIP_TRY(h, hipMemsetAsync(h->init.p, 0, dim * 16, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->init.p, one, 16, hipMemcpyHostToDevice, h->stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VQE_OK;
+}
+
+int vqe_set_hamiltonian_pauli(vqe_t* h, int n_terms, const uint64_t* xmask, const uint64_t* zmask,
+                              const double* coeff) {
+  if (!h) return VQE_EINVAL;
+  if (n_terms < 0 || (n_terms > 0 && (!xmask || !zmask || !coeff)))
+    return fail(h, VQE_EINVAL, "bad Hamiltonian arguments");
+  HIP_TRY(h, hipSetDevice(h->dev));
+  const uint64_t lim = h->n >= 64 ? ~0ull : (((uint64_t)1 << h->n) - 1);
+  h->hx.assign(xmask, xmask + n_terms);
+  h->hz.assign(zmask, zmask + n_terms);
+  h->hcr.assign(n_terms, 0.0);
+  h->hci.assign(n_terms, 0.0);
+  std::map<uint32_t, int> index;
+  h->gx_all.clear();
+  h->group_terms.clear();
+  for (int k = 0; k < n_terms; ++k) {
+    if ((xmask[k] | zmask[k]) & ~lim) return fail(h, VQE_EINVAL, "Pauli mask uses a qubit >= n_qubits");
+    const int ny = __builtin_popcountll(xmask[k] & zmask[k]) & 3;  // i^{#Y}
+    const double w = coeff[k];
+    h->hcr[k] = ny == 0 ? w : (ny == 2 ? -w : 0.0);
+    h->hci[k] = ny == 1 ? w : (ny == 3 ? -w : 0.0);
+    const uint32_t x = (uint32_t)xmask[k];
+    auto it = index.find(x);
+    if (it == index.end()) {
+      it = index.emplace(x, (int)h->gx_all.size()).first;
+      h->gx_all.push_back(x);
+      h->group_terms.emplace_back();
+    }
+    h->group_terms[it->second].push_back(k);
+  }
+  h->ham_set = true;
+  return build_hamiltonian(h);
+}
+
+int vqe_set_term_shard(vqe_t* h, int rank, int world) {
+  if (!h) return VQE_EINVAL;
+  if (world < 1 || rank < 0 || rank >= world) return fail(h, VQE_EINVAL, "bad shard rank/world");
+  h->shard_rank = rank;
+  h->shard_world = world;
+  if (h->ham_set) { HIP_TRY(h, hipSetDevice(h->dev)); return build_hamiltonian(h); }
+  return VQE_OK;
+}
+
+int vqe_set_noise(vqe_t* h, double p1, double p2, uint64_t seed) {
+  if (!h) return VQE_EINVAL;
+  if (!(p1 >= 0.0 && p1 <= 1.0 && p2 >= 0.0 && p2 <= 1.0)) return fail(h, VQE_EINVAL, "noise probability outside [0,1]");
+  h->noise = NoiseCfg{p1, p2, seed, 0ull};
+  return VQE_OK;
+}
+
+int vqe_set_circuit(vqe_t* h, int n_gates, const int32_t* kind, const int32_t* q0, const int32_t* q1,
+                    const int32_t* pidx, int n_params) {
+  if (!h) return VQE_EINVAL;
+  if (n_gates < 0 || n_params < 0 || (n_gates > 0 && (!kind || !q0 || !q1 || !pidx)))
+    return fail(h, VQE_EINVAL, "bad circuit arguments");
+  int rc = check_gates(h, n_gates, kind, q0, q1, pidx, n_params);
+  if (rc) return rc;
+  h->circ.resize(n_gates);
+  for (int i = 0; i < n_gates; ++i) h->circ[i] = GateRec{kind[i], q0[i], q1[i], pidx[i]};
+  h->circ_params = n_params;
+  return VQE_OK;
+}
+
+int vqe_energy_batch(vqe_t* h, int batch, const double* theta, double* energy) {
+  if (!h) return VQE_EINVAL;
+  if (batch < 1 || !energy || (h->circ_params > 0 && !theta)) return fail(h, VQE_EINVAL, "bad arguments");
+  HIP_TRY(h, hipSetDevice(h->dev));
+  int rc = load_single(h, batch, theta);
+  if (rc) return rc;
+  if ((rc = ready(h))) return rc;
+  if ((rc = run(h, 0, 0, 0, 0))) return rc;
+  HIP_TRY(h, hipMemcpyAsync(energy, h->d_f.p, (size_t)batch * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VQE_OK;
+}
+
+int vqe_energy(vqe_t* h, const double* theta, double* energy) { return vqe_energy_batch(h, 1, theta, energy); }
+
+int vqe_get_state(vqe_t* h, const double* theta, double* amps) {
+  if (!h) return VQE_EINVAL;
+  if (!amps || (h->circ_params > 0 && !theta)) return fail(h, VQE_EINVAL, "bad arguments");
+  HIP_TRY(h, hipSetDevice(h->dev));
+  int rc = load_single(h, 1, theta);
+  if (rc) return rc;
+  const size_t dim = (size_t)1 << h->n;
+  HIP_TRY(h, h->d_state.reserve(dim));
+  if ((rc = run(h, 2, 0, 0, 0))) return rc;
+  HIP_TRY(h, hipMemcpyAsync(amps, h->d_state.p, dim * 16, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VQE_OK;
+}
+
+int vqe_minimize_cobyla(vqe_t* h, const double* x0, double rhobeg, double rhoend, int maxfun, double* x,
+                        double* f, int32_t* nfev) {
+  if (!h) return VQE_EINVAL;
+  if (maxfun < 1 || !(rhobeg > 0) || !(rhoend > 0)) return fail(h, VQE_EINVAL, "bad COBYLA arguments");
+  if (h->circ_params > 0 && (!x0 || !x)) return fail(h, VQE_EINVAL, "x0/x is NULL");
+  HIP_TRY(h, hipSetDevice(h->dev));
+  int rc = load_single(h, 1, x0);
+  if (rc) return rc;
+  if ((rc = ready(h))) return rc;
+  if ((rc = run(h, 1, rhobeg, rhoend, maxfun))) return rc;
+  return vqe_batch_fetch(h, x, f, nfev);
+}
+
+int vqe_batch_load(vqe_t* h, int batch, const int64_t* gate_off, const int32_t* kind, const int32_t* q0,
+                   const int32_t* q1, const int32_t* pidx, const int64_t* par_off, const double* theta0) {
+  if (!h) return VQE_EINVAL;
+  if (batch < 1 || !gate_off || !par_off) return fail(h, VQE_EINVAL, "bad batch arguments");
+  HIP_TRY(h, hipSetDevice(h->dev));
+  const int64_t G = gate_off[batch], PT = par_off[batch];
+  if (gate_off[0] != 0 || par_off[0] != 0 || G < 0 || PT < 0) return fail(h, VQE_EINVAL, "offsets must start at 0");
+  if ((G > 0 && (!kind || !q0 || !q1 || !pidx)) || (PT > 0 && !theta0)) return fail(h, VQE_EINVAL, "NULL array");
+  std::vector<GateRec> gates((size_t)G);
+  std::vector<int64_t> gbeg(batch), pbeg(batch);
+  std::vector<int32_t> gcnt(batch), pcnt(batch);
+  for (int b = 0; b < batch; ++b) {
+    const int64_t g0 = gate_off[b], g1 = gate_off[b + 1], p0 = par_off[b], p1 = par_off[b + 1];
+    if (g1 < g0 || p1 < p0 || g1 > G || p1 > PT) return fail(h, VQE_EINVAL, "offsets not monotone");
+    int rc = check_gates(h, g1 - g0, kind + g0, q0 + g0, q1 + g0, pidx + g0, (int)(p1 - p0));
+    if (rc) return rc;
+    gbeg[b] = g0; gcnt[b] = (int32_t)(g1 - g0); pbeg[b] = p0; pcnt[b] = (int32_t)(p1 - p0);
+  }
+  for (int64_t i = 0; i < G; ++i) gates[i] = GateRec{kind[i], q0[i], q1[i], pidx[i]};
+  return load_batch(h, batch, gates, gbeg, gcnt, pbeg, pcnt, theta0, PT);
+}
+
+int vqe_batch_run_energy(vqe_t* h) {
+  int rc = ready(h);
+  if (rc) return rc;
+  return run(h, 0, 0, 0, 0);
+}
+
+int vqe_batch_run_minimize(vqe_t* h, double rhobeg, double rhoend, int maxfun) {
+  int rc = ready(h);
+  if (rc) return rc;
+  if (maxfun < 1 || !(rhobeg > 0) || !(rhoend > 0)) return fail(h, VQE_EINVAL, "bad COBYLA arguments");
+  return run(h, 1, rhobeg, rhoend, maxfun);
+}
+
+int vqe_batch_fetch(vqe_t* h, double* x, double* f, int32_t* nfev) {
+  if (!h) return VQE_EINVAL;
+  if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
+  HIP_TRY(h, hipSetDevice(h->dev));
+  if (x && h->total_params)
+    HIP_TRY(h, hipMemcpyAsync(x, h->d_theta.p, (size_t)h->total_params * 8, hipMemcpyDeviceToHost, h->stream));
+  if (f) HIP_TRY(h, hipMemcpyAsync(f, h->d_f.p, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
+  if (nfev) HIP_TRY(h, hipMemcpyAsync(nfev, h->d_nfev.p, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VQE_OK;
+}
+
+int vqe_batch_energy_devptr(vqe_t* h, void** p) {
+  if (!h || !p) return VQE_EINVAL;
+  if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
+  *p = h->d_f.p;
+  return VQE_OK;
+}
+
+int vqe_last_kernel_ms(vqe_t* h, float* ms) {
+  if (!h || !ms) return VQE_EINVAL;
+  HIP_TRY(h, hipEventSynchronize(h->ev1));
+  HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return VQE_OK;
+}
+
+// ---- host COBYLA ---------------------------------------------------------------------------
+struct vqe_cobyla {
+  cby::CobylaM0<cby::HostCtx, true> c;
+  std::vector<double> mem;
+  int n = 0, want = 0, nfev = 0;
+  double flast = 0.0;
+  bool finished = false;
+};
+
+int vqe_cobyla_create(int n, const double* x0, double rhobeg, double rhoend, int maxfun, vqe_cobyla_t** out) {
+  if (!out || n < 0 || (n > 0 && !x0) || maxfun < 1 || !(rhobeg > 0) || !(rhoend > 0)) return VQE_EINVAL;
+  vqe_cobyla* c = new (std::nothrow) vqe_cobyla;
+  if (!c) return VQE_ENOMEM;
+  c->n = n;
+  c->mem.assign(cby::scratch_doubles(n) + 8, 0.0);
+  c->c.bind(c->mem.data(), n);
+  for (int i = 0; i < n; ++i) c->c.x[i] = x0[i];
+  if (n == 0) { c->want = 1; c->c.nfvals = 1; c->c.status = cby::RUNNING; }
+  else c->want = c->c.start(rhobeg, rhoend, maxfun);
+  *out = c;
+  return VQE_OK;
+}
+
+int vqe_cobyla_ask(vqe_cobyla_t* c, double* x) {
+  if (!c) return VQE_EINVAL;
+  if (!c->want) return 0;
+  if (x) for (int i = 0; i < c->n; ++i) x[i] = c->c.x[i];
+  return 1;
+}
+
+int vqe_cobyla_tell(vqe_cobyla_t* c, double f) {
+  if (!c || !c->want) return VQE_ESTATE;
+  c->flast = f;
+  if (c->n == 0) { c->want = 0; c->c.status = cby::DONE_RHOEND; c->c.ifull = 1; return 0; }
+  c->want = c->c.tell(f);
+  return c->want;
+}
+
+int vqe_cobyla_result(vqe_cobyla_t* c, double* x, double* f, int32_t* nfev, int32_t* status) {
+  if (!c) return VQE_EINVAL;
+  if (x) for (int i = 0; i < c->n; ++i) x[i] = c->c.x[i];
+  if (f) *f = (c->c.status == cby::DONE_RHOEND && c->c.ifull == 1) ? c->flast : c->c.fbest_ret;
+  if (nfev) *nfev = c->c.nfvals;
+  if (status) *status = c->c.status;
+  return VQE_OK;
+}
+
+void vqe_cobyla_destroy(vqe_cobyla_t* c) { delete c; }
+
+}  // extern "C"

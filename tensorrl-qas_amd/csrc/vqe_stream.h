@@ -1,0 +1,287 @@
+// vqe_stream.h - HBM-streaming path for n >= 14 qubits (state vector does not fit LDS).
+//
+// Every evaluation stream keeps its 2^n complex128 amplitudes in HBM (16 MiB at n = 20).
+// The same affine GF(2) bookkeeping as the LDS path removes every CNOT; each remaining
+// rotation is one coalesced read-modify-write sweep (32 * 2^n bytes).  The energy kernel
+// transforms the Pauli masks into the physical layout instead of permuting the state, reads
+// each amplitude once plus one partner amplitude per X-mask group, evaluates the sign sums
+// on the fly and reduces per block; a second tiny kernel sums the block partials in a fixed
+// order (bitwise reproducible, no atomics).  The COBYLA loop of this path is host driven
+// (vqe_cobyla ask/tell) because with Pauli-term sharding every evaluation ends in a
+// collective.
+#pragma once
+#include <string>
+#include <vector>
+#include "vqe_device.h"
+
+namespace vqe {
+
+struct StreamWork {
+  double2* states = nullptr;  size_t states_cap = 0;   // [batch][2^n]
+  Op* ops = nullptr;          size_t ops_cap = 0;      // [batch][max_ops]
+  uint32_t* masks = nullptr;  size_t masks_cap = 0;    // [batch][64]: xm[32], zm[32]
+  int32_t* meta = nullptr;    size_t meta_cap = 0;     // [batch][8]
+  double2* cs = nullptr;      size_t cs_cap = 0;       // [batch][max_params]
+  uint32_t* gxp = nullptr;    size_t gxp_cap = 0;      // [batch][n_groups] physical X masks
+  uint32_t* tzp = nullptr;    size_t tzp_cap = 0;      // [batch][n_terms] physical Z masks
+  double* tsg = nullptr;      size_t tsg_cap = 0;      // [batch][n_terms] (-1)^{z.c}
+  double* partial = nullptr;  size_t partial_cap = 0;  // [batch][blocks]
+  ~StreamWork() {
+    (void)hipFree(states); (void)hipFree(ops); (void)hipFree(masks); (void)hipFree(meta);
+    (void)hipFree(cs); (void)hipFree(gxp); (void)hipFree(tzp); (void)hipFree(tsg); (void)hipFree(partial);
+  }
+};
+
+template <class T>
+inline hipError_t sw_reserve(T*& p, size_t& cap, size_t n) {
+  if (n <= cap) return hipSuccess;
+  if (p) (void)hipFree(p);
+  p = nullptr; cap = 0;
+  hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+  if (e == hipSuccess) cap = n;
+  return e;
+}
+
+struct GlobalCompileTarget {  // compile_ops writes through the same field names as Lds
+  Op* ops; uint32_t* xm; int32_t* meta;
+};
+
+// one thread per stream: gate list -> ops (+ zm rows, needed to move the Pauli masks)
+__global__ void k_s_compile(BatchArgs A, Op* ops, uint32_t* masks, int32_t* meta, uint64_t eval_id) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= A.batch) return;
+  const int n = A.n;
+  uint32_t* xm = masks + (size_t)b * 64;
+  uint32_t* zm = xm + 32;
+  Op* out = ops + (size_t)b * A.max_ops;
+  for (int q = 0; q < n; ++q) { xm[q] = 1u << q; zm[q] = 1u << q; }
+  uint32_t c = 0;
+  int phase = 0, nops = 0;
+  const GateRec* g = A.gates + A.gate_begin[b];
+  const int G = A.gate_count[b];
+  auto pauli = [&](int q, int p) {
+    if (p == 0) return;
+    if (p == 1 || p == 2) c ^= 1u << q;
+    if (p == 2 || p == 3) {
+      if (nops < A.max_ops) out[nops] = Op{0u, zm[q], -1, OP_PZ | (int)(((c >> q) & 1u) << 8)};
+      ++nops;
+    }
+    if (p == 2) phase = (phase + 3) & 3;
+  };
+  for (int i = 0; i < G; ++i) {
+    const GateRec r = g[i];
+    if (r.kind == G_CNOT) {
+      zm[r.q1] ^= zm[r.q0];
+      xm[r.q0] ^= xm[r.q1];
+      if ((c >> r.q0) & 1u) c ^= 1u << r.q1;
+    } else if (r.kind >= G_RX && r.kind <= G_RZ) {
+      if (nops < A.max_ops)
+        out[nops] = Op{xm[r.q0], zm[r.q0], r.pidx, r.kind | (int)(((c >> r.q0) & 1u) << 8)};
+      ++nops;
+    } else if (r.kind == G_DEPOL1) {
+      const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
+      if (u < A.noise.p1) pauli(r.q0, 1 + (int)(u / A.noise.p1 * 3.0));
+    } else if (r.kind == G_DEPOL2) {
+      const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
+      if (u < A.noise.p2) {
+        const int idx = 1 + (int)(u / A.noise.p2 * 15.0);
+        pauli(r.q0, idx & 3);
+        pauli(r.q1, idx >> 2);
+      }
+    }
+  }
+  int32_t* m = meta + (size_t)b * 8;
+  m[0] = nops < A.max_ops ? nops : A.max_ops;
+  m[1] = (int32_t)c;
+  m[2] = phase;
+}
+
+__global__ void k_s_sincos(BatchArgs A, double2* cs) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.par_count[b]) return;
+  double s, c;
+  sincos(0.5 * A.theta[A.par_begin[b] + j], &s, &c);
+  cs[(size_t)b * A.max_params + j] = make_double2(c, s);
+}
+
+__global__ void __launch_bounds__(kThreads) k_s_init(BatchArgs A, double2* states) {
+  const size_t dim = (size_t)1 << A.n;
+  const size_t p = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (p < dim) states[(size_t)blockIdx.y * dim + p] = A.init[p];
+}
+
+// op number `o` of every stream: one pair (or two neighbouring amplitudes) per thread
+__global__ void __launch_bounds__(kThreads) k_s_op(BatchArgs A, double2* states, const Op* ops,
+                                                   const int32_t* meta, const double2* cs, int o) {
+  const int b = blockIdx.y;
+  if (o >= meta[(size_t)b * 8]) return;
+  const Op op = ops[(size_t)b * A.max_ops + o];
+  const int kind = op.kind & 0xff, inv = (op.kind >> 8) & 1;
+  const size_t dim = (size_t)1 << A.n;
+  double2* psi = states + (size_t)b * dim;
+  const uint32_t q = blockIdx.x * kThreads + threadIdx.x;
+  if (q >= dim / 2) return;
+  if (kind == OP_RX || kind == OP_RY) {
+    const double2 c = cs[(size_t)b * A.max_params + op.pidx];
+    const int hb = 31 - __clz((int)op.xm);
+    const uint32_t p0 = insert0(q, hb), p1 = p0 ^ op.xm;
+    const double2 a0 = psi[p0], a1 = psi[p1];
+    if (kind == OP_RX) {
+      psi[p0] = make_double2(c.x * a0.x - c.y * a1.y, c.x * a0.y + c.y * a1.x);
+      psi[p1] = make_double2(c.x * a1.x - c.y * a0.y, c.x * a1.y + c.y * a0.x);
+    } else {
+      const double s0 = (parity32(p0 & op.zm) ^ inv) ? -c.y : c.y;
+      psi[p0] = make_double2(c.x * a0.x + s0 * a1.x, c.x * a0.y + s0 * a1.y);
+      psi[p1] = make_double2(c.x * a1.x - s0 * a0.x, c.x * a1.y - s0 * a0.y);
+    }
+  } else if (kind == OP_RZ) {
+    const double2 c = cs[(size_t)b * A.max_params + op.pidx];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t p = 2 * q + k;
+      const double s = (parity32(p & op.zm) ^ inv) ? -c.y : c.y;
+      const double2 a = psi[p];
+      psi[p] = make_double2(c.x * a.x - s * a.y, c.x * a.y + s * a.x);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t p = 2 * q + k;
+      if (parity32(p & op.zm) ^ inv) { const double2 a = psi[p]; psi[p] = make_double2(-a.x, -a.y); }
+    }
+  }
+}
+
+// Pauli masks of the Hamiltonian expressed in each stream's physical layout.
+__global__ void k_s_terms(BatchArgs A, const uint32_t* masks, const int32_t* meta, int n_terms,
+                          uint32_t* gxp, uint32_t* tzp, double* tsg) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t* xm = masks + (size_t)b * 64;
+  const uint32_t* zm = xm + 32;
+  const uint32_t c = (uint32_t)meta[(size_t)b * 8 + 1];
+  if (i < A.ham.n_groups) {
+    const uint32_t x = A.ham.gx[i];
+    uint32_t xp = 0;
+    for (int q = 0; q < A.n; ++q) if ((x >> q) & 1u) xp ^= xm[q];
+    gxp[(size_t)b * A.ham.n_groups + i] = xp;
+  }
+  if (i < n_terms) {
+    const uint32_t z = A.ham.term_z[i];
+    uint32_t zp = 0;
+    for (int q = 0; q < A.n; ++q) if ((z >> q) & 1u) zp ^= zm[q];
+    tzp[(size_t)b * n_terms + i] = zp;
+    tsg[(size_t)b * n_terms + i] = parity32(z & c) ? -1.0 : 1.0;
+  }
+}
+
+constexpr int kEnergyApt = 4;  // amplitudes per thread in the energy sweep
+
+__global__ void __launch_bounds__(kThreads) k_s_energy(BatchArgs A, const double2* states, int n_terms,
+                                                       const uint32_t* gxp, const uint32_t* tzp,
+                                                       const double* tsg, double* partial) {
+  __shared__ double red[8];
+  const int b = blockIdx.y;
+  const size_t dim = (size_t)1 << A.n;
+  const double2* psi = states + (size_t)b * dim;
+  const uint32_t* gx = gxp + (size_t)b * A.ham.n_groups;
+  const uint32_t* tz = tzp + (size_t)b * n_terms;
+  const double* ts = tsg + (size_t)b * n_terms;
+  const uint32_t base = blockIdx.x * (kThreads * kEnergyApt) + threadIdx.x;
+  double2 own[kEnergyApt];
+#pragma unroll
+  for (int k = 0; k < kEnergyApt; ++k) own[k] = psi[base + k * kThreads];
+  double acc = 0.0;
+  for (int g = 0; g < A.ham.n_groups; ++g) {
+    const uint32_t x = gx[g];
+    const int t0 = A.ham.term_off[g], t1 = A.ham.term_off[g + 1];
+#pragma unroll
+    for (int k = 0; k < kEnergyApt; ++k) {
+      const uint32_t p = base + k * kThreads;
+      const double2 bb = own[k];
+      const double2 a = x ? psi[p ^ x] : bb;
+      double dr = 0.0, di = 0.0;
+      for (int t = t0; t < t1; ++t) {
+        const double s = parity32(p & tz[t]) ? -ts[t] : ts[t];
+        dr += s * A.ham.term_cr[t];
+        di += s * A.ham.term_ci[t];
+      }
+      acc += (a.x * bb.x + a.y * bb.y) * dr - (a.x * bb.y - a.y * bb.x) * di;
+    }
+  }
+  const double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(kThreads) k_s_reduce(const double* partial, int nblk, double* fout) {
+  __shared__ double red[8];
+  const int b = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += kThreads) acc += partial[(size_t)b * nblk + i];
+  const double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) fout[b] = tot;
+}
+
+// logical-layout copy of stream 0 for vqe_get_state
+__global__ void __launch_bounds__(kThreads) k_s_state_out(BatchArgs A, const double2* states,
+                                                          const uint32_t* masks, const int32_t* meta) {
+  const size_t dim = (size_t)1 << A.n;
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= dim) return;
+  const uint32_t c = (uint32_t)meta[1];
+  const int ph = meta[2];
+  uint32_t v = i ^ c, p = 0;
+  for (int q = 0; q < A.n; ++q) if ((v >> q) & 1u) p ^= masks[q];
+  double2 a = states[p];
+  if (ph == 1) a = make_double2(-a.y, a.x);
+  else if (ph == 2) a = make_double2(-a.x, -a.y);
+  else if (ph == 3) a = make_double2(a.y, -a.x);
+  A.state_out[i] = a;
+}
+
+#define SW_TRY(expr)                                                            \
+  do {                                                                          \
+    hipError_t _e = (expr);                                                     \
+    if (_e != hipSuccess) {                                                     \
+      err = std::string(#expr) + ": " + hipGetErrorString(_e);                  \
+      return _e == hipErrorOutOfMemory ? -12 : -5;                              \
+    }                                                                           \
+  } while (0)
+
+// circuit + (partial) energy of every resident stream, results in A.fout (device)
+inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipStream_t st,
+                           uint64_t eval_id, bool want_energy, std::string& err) {
+  const size_t dim = (size_t)1 << A.n;
+  const int B = A.batch;
+  SW_TRY(sw_reserve(sw.states, sw.states_cap, (size_t)B * dim));
+  SW_TRY(sw_reserve(sw.ops, sw.ops_cap, (size_t)B * A.max_ops));
+  SW_TRY(sw_reserve(sw.masks, sw.masks_cap, (size_t)B * 64));
+  SW_TRY(sw_reserve(sw.meta, sw.meta_cap, (size_t)B * 8));
+  SW_TRY(sw_reserve(sw.cs, sw.cs_cap, (size_t)B * A.max_params));
+  const int nt = n_terms > 0 ? n_terms : 1, ng = A.ham.n_groups > 0 ? A.ham.n_groups : 1;
+  SW_TRY(sw_reserve(sw.gxp, sw.gxp_cap, (size_t)B * ng));
+  SW_TRY(sw_reserve(sw.tzp, sw.tzp_cap, (size_t)B * nt));
+  SW_TRY(sw_reserve(sw.tsg, sw.tsg_cap, (size_t)B * nt));
+  const int eblk = (int)(dim / (kThreads * kEnergyApt));
+  SW_TRY(sw_reserve(sw.partial, sw.partial_cap, (size_t)B * eblk));
+
+  hipLaunchKernelGGL(k_s_compile, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.masks, sw.meta, eval_id);
+  hipLaunchKernelGGL(k_s_sincos, dim3((A.max_params + 63) / 64, B), dim3(64), 0, st, A, sw.cs);
+  hipLaunchKernelGGL(k_s_init, dim3((unsigned)(dim / kThreads), B), dim3(kThreads), 0, st, A, sw.states);
+  for (int o = 0; o < A.max_ops; ++o)
+    hipLaunchKernelGGL(k_s_op, dim3((unsigned)(dim / 2 / kThreads), B), dim3(kThreads), 0, st, A, sw.states,
+                       sw.ops, sw.meta, sw.cs, o);
+  if (want_energy) {
+    const int m = std::max(nt, ng);
+    hipLaunchKernelGGL(k_s_terms, dim3((m + 63) / 64, B), dim3(64), 0, st, A, sw.masks, sw.meta, n_terms,
+                       sw.gxp, sw.tzp, sw.tsg);
+    hipLaunchKernelGGL(k_s_energy, dim3(eblk, B), dim3(kThreads), 0, st, A, sw.states, n_terms, sw.gxp,
+                       sw.tzp, sw.tsg, sw.partial);
+    hipLaunchKernelGGL(k_s_reduce, dim3(B), dim3(kThreads), 0, st, sw.partial, eblk, A.fout);
+  }
+  SW_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace vqe

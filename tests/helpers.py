@@ -1,0 +1,64 @@
+"""Shared test helpers: fixtures -> oracle / engine inputs."""
+import json
+import os
+
+import numpy as np
+
+import vqe_oracle as vo
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ("H2O_8q", "CH2_8q", "BEH2_6q", "heisenberg_5q")
+NAME = {0: "cx", 1: "rx", 2: "ry", 3: "rz"}
+
+
+def known_answers():
+    return json.load(open(os.path.join(GOLDEN, "known_answers.json")))
+
+
+def load_case(case):
+    d = np.load(os.path.join(GOLDEN, f"ham_{case}.npz"))
+    n = int(d["n"])
+    gates = []
+    for nm, a, b, ang in zip(d["gate_name"], d["gate_q0"], d["gate_q1"], d["gate_angle"]):
+        nm = NAME[int(nm)]
+        gates.append((nm, [int(a), int(b)] if nm == "cx" else [int(a)], None if nm == "cx" else float(ang)))
+    return {"n": n, "paulis": [str(s) for s in d["paulis"]], "weights": np.asarray(d["weights"], float),
+            "eigvals": np.asarray(d["eigvals"], float), "gates": gates}
+
+
+def oracle_init_state(case_data):
+    n = case_data["n"]
+    k, a, b, p, th = vo.qasm_to_gatelist(case_data["gates"])
+    psi0 = np.zeros(2 ** n, np.complex128)
+    psi0[0] = 1
+    return vo.run_circuit(psi0, k, a, b, p, th)
+
+
+def random_gates(n, G, rng, p_cnot=0.5):
+    kind, q0, q1, pidx, th = [], [], [], [], []
+    for _ in range(G):
+        if rng.random() < p_cnot and n > 1:
+            c = int(rng.integers(n))
+            t = int((c + 1 + rng.integers(n - 1)) % n)
+            kind.append(0), q0.append(c), q1.append(t), pidx.append(-1)
+        else:
+            kind.append(1 + int(rng.integers(3))), q0.append(int(rng.integers(n))), q1.append(-1)
+            pidx.append(len(th)), th.append(float(rng.uniform(-np.pi, np.pi)))
+    return (np.array(kind, np.int32), np.array(q0, np.int32), np.array(q1, np.int32),
+            np.array(pidx, np.int32), np.array(th, np.float64))
+
+
+def random_state(n, rng):
+    v = rng.normal(size=2 ** n) + 1j * rng.normal(size=2 ** n)
+    return v / np.linalg.norm(v)
+
+
+def random_hamiltonian(n, T, rng, real=True):
+    """Random Pauli sum; ``real=True`` keeps #Y even (real symmetric matrix)."""
+    xs, zs, cs = [], [], []
+    while len(xs) < T:
+        x, z = int(rng.integers(2 ** n)), int(rng.integers(2 ** n))
+        if real and bin(x & z).count("1") % 2:
+            continue
+        xs.append(x), zs.append(z), cs.append(float(rng.normal()))
+    return np.array(xs, np.uint64), np.array(zs, np.uint64), np.array(cs)
