@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Benchmark of the VQE environment-step hot path (BASELINE.json metric: VQE env-steps/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One bench *step* = one CircuitEnv.step() worth of arithmetic for every one of the B parallel
+environments of a rank, in one fused launch: COBYLA (scipy-1.15 defaults rhobeg=1, rhoend=1e-4,
+maxfun=1000) on the pre-action circuit, float32 round-trip of the angles, energy of the
+post-action circuit (reference environments/environment_qulacs_TN_notin_agent.py:283-291).
+
+Workload (SURVEY.md section 8d, config "12-qubit LiH TensorRL_fixed noiseless"): SYNTHETIC
+LiH-like 631-term Pauli Hamiltonian (the reference never shipped LiH-12q), brickwork chi=2
+stand-in initial state, random circuits of G gates (half CNOTs, half R{X,Y,Z}, theta ~
+U(-pi, pi) rounded to float32), the last gate being the "new" one.  Inputs are resident in
+HBM before the timed region and are not modified by a step, so every step does identical
+work.  Multi-GPU: environments are sharded over ranks (replicas, no data-path collective,
+weak scaling); the auxiliary ``heis20`` object times the 20-qubit Heisenberg <H> with Pauli
+terms sharded over the ranks and ONE RCCL all-reduce of the partial energies.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_QUBITS = 12
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_batch(tq, n, B, G, seed):
+    """B random circuits of G gates (SURVEY 8d generator), vectorised."""
+    rng = np.random.default_rng(seed)
+    is_cnot = rng.random((B, G)) < 0.5
+    c = rng.integers(0, n, (B, G))
+    t = (c + 1 + rng.integers(0, n - 1, (B, G))) % n
+    rq = rng.integers(0, n, (B, G))
+    rk = rng.integers(1, 4, (B, G))
+    kind = np.where(is_cnot, 0, rk).astype(np.int32)
+    q0 = np.where(is_cnot, c, rq).astype(np.int32)
+    q1 = np.where(is_cnot, t, -1).astype(np.int32)
+    rot = ~is_cnot
+    pidx = np.where(rot, np.cumsum(rot, axis=1) - 1, -1).astype(np.int32)
+    pcount = rot.sum(axis=1)
+    gate_off = np.arange(B + 1, dtype=np.int64) * G
+    par_off = np.concatenate([[0], np.cumsum(pcount)]).astype(np.int64)
+    theta = rng.uniform(-np.pi, np.pi, int(par_off[-1])).astype(np.float32).astype(np.float64)
+    # the new gate is the last one; a new rotation enters with angle 0 (reference step())
+    last_rot = rot[:, -1]
+    theta[par_off[1:][last_rot] - 1] = 0.0
+    new_gate = np.full(B, G - 1, np.int32)
+    return dict(gate_off=gate_off, kind=kind.ravel(), q0=q0.ravel(), q1=q1.ravel(), pidx=pidx.ravel(),
+                par_off=par_off, theta=theta, new_gate=new_gate, pcount=pcount)
+
+
+def cpu_baseline(tq, ham, psi0, batch, G, n_steps, maxfun):
+    """Reference algorithm on the host cores for a bounded sample of the same workload:
+    C restatement of the qulacs gate sweeps (oracle/vqe_oracle.c) + the literal dense
+    numpy expression (VQE_qulacs_TN_notin_RL.py:86) inside scipy's COBYLA (:478)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle as co
+    import vqe_oracle as vo
+    from scipy.optimize import minimize
+    n = N_QUBITS
+    idx = np.arange(2 ** n)
+    dense = np.zeros((2 ** n, 2 ** n), np.complex128)
+    for x, z, w in zip(ham.xmask, ham.zmask, ham.coeff):
+        x, z = int(x), int(z)
+        ny = bin(x & z).count("1")
+        dense[idx ^ x, idx] += w * (1.0 - 2.0 * vo._parity(idx & z)) * (1j ** ny)
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    evals = 0
+    t0 = time.perf_counter()
+    for b in range(n_steps):
+        g0, g1 = batch["gate_off"][b], batch["gate_off"][b + 1]
+        p0, p1 = batch["par_off"][b], batch["par_off"][b + 1]
+        kind, q0, q1, pidx = (batch[k][g0:g1] for k in ("kind", "q0", "q1", "pidx"))
+        th = batch["theta"][p0:p1].copy()
+        pre = slice(0, G - 1)
+        hole = int(pidx[-1])
+        x0 = th if hole < 0 else th[:hole]          # the new rotation is the last parameter
+
+        def cost(x, k=kind[pre], a=q0[pre], bq=q1[pre], p=pidx[pre]):
+            psi = co.run_circuit(n, psi0, k, a, bq, p, x)
+            return float((np.conj(psi).T @ dense @ psi).real)
+
+        r = minimize(cost, x0, method="COBYLA", options={"maxiter": maxfun})
+        full = th.copy()
+        full[:x0.size] = r.x.astype(np.float32)
+        psi = co.run_circuit(n, psi0, kind, q0, q1, pidx, full)
+        _ = float((np.conj(psi).T @ dense @ psi).real)
+        evals += r.nfev + 1
+    dt = time.perf_counter() - t0
+    return {"value": n_steps / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n_steps} env-steps of the same batch ({evals} evaluations, {dt:.1f} s): C gate sweeps "
+                      f"+ numpy dense (conj(psi)@H)@psi + scipy {__import__('scipy').__version__} COBYLA",
+            "evals_per_s": evals / dt}
+
+
+def heis20_aux(tq, torch, dist, rank, world, dev, steps):
+    """20-qubit Heisenberg <H>: every rank applies the same circuits, evaluates its share of
+    the X-mask groups, one all-reduce (RCCL) sums the partial energies.  Strong scaling of
+    the Pauli-term reduction."""
+    n, B, G = 20, 8, 32
+    ham, _ = tq.hamiltonian.heisenberg(n)
+    eng = tq.VQEEngine(n, dev)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_hamiltonian(ham.xmask, ham.zmask, ham.coeff)
+    eng.set_term_shard(rank, world)
+    batch = make_batch(tq, n, B, G, 2020)
+    eng.batch_load_flat(batch["gate_off"], batch["kind"], batch["q0"], batch["q1"], batch["pidx"],
+                        batch["par_off"], batch["theta"])
+    e = torch.zeros(B, dtype=torch.float64, device=f"cuda:{dev}")
+
+    def one():
+        eng.batch_run_energy()
+        eng.batch_copy_energy(e.data_ptr())
+        if world > 1:
+            dist.all_reduce(e)
+
+    one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {"workload": "heisenberg_20q_77terms_G32_B8_term_sharded", "evals_per_s": B * steps / float(t.item()),
+            "energy_checksum": float(e.sum().item()), "scaling": "strong"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=2048, help="parallel environments per GPU")
+    ap.add_argument("--gates", type=int, default=64, help="gates per synthetic circuit")
+    ap.add_argument("--maxfun", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-heis20", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import tensorrl_qas_amd as tq
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the VQE engine has no CPU fallback")
+    torch.cuda.set_device(local)
+    torch.cuda.set_stream(torch.cuda.Stream())   # one explicit stream for the engine, copies and RCCL
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+
+    n, B, G = N_QUBITS, args.envs, args.gates
+    ham = tq.hamiltonian.synthetic_lih12()
+    psi0 = tq.hamiltonian.brickwork_state(n, 12)
+    eng = tq.VQEEngine(n, local)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_init_state(psi0)
+    eng.set_hamiltonian(ham.xmask, ham.zmask, ham.coeff)
+    batch = make_batch(tq, n, B, G, 1000 + rank)
+    eng.batch_load_flat(batch["gate_off"], batch["kind"], batch["q0"], batch["q1"], batch["pidx"],
+                        batch["par_off"], batch["theta"])
+    eng.batch_set_new_gate(batch["new_gate"])
+
+    def step():
+        eng.batch_run_env_step(1.0, 1e-4, args.maxfun)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    # kernel duration (HIP events on the launch stream) of the last step, and its work
+    k_ms = eng.last_kernel_ms()
+    _, f, nfev = eng.batch_fetch(want_x=False)
+    evals_per_launch = int(nfev.sum()) + B          # + the final post-action evaluation
+    T, Tx = ham.n_terms, ham.n_xgroups
+    bytes_per_eval = (2 ** n) * 16 * (2 * (G - 1) + T)          # 2^n*16*(2G+T)
+    bytes_per_eval_grouped = (2 ** n) * 16 * (2 * (G - 1) + Tx)
+    achieved = evals_per_launch * bytes_per_eval / (k_ms * 1e-3) / 1e9
+    stats = torch.tensor([float(nfev.sum()), float(B)], dtype=torch.float64, device=f"cuda:{local}")
+    if world > 1:
+        dist.all_reduce(stats)
+    mean_nfev = float(stats[0].item() / stats[1].item())
+
+    heis = None
+    if not args.no_heis20:
+        heis = heis20_aux(tq, torch, dist, rank, world, local, max(2, args.steps))
+
+    if rank == 0:
+        out = {
+            "metric": "VQE env-steps/sec", "value": world * B * args.steps / dt, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"lih12_synthetic631_fixed_noiseless_G{G}_B{B}_per_gpu",
+                       "n_qubits": n, "pauli_terms": T, "x_groups": Tx, "gates": G, "envs_per_gpu": B,
+                       "cobyla": {"rhobeg": 1.0, "rhoend": 1e-4, "maxfun": args.maxfun},
+                       "mean_nfev": mean_nfev, "parallelism": f"env-replicas x{world}"},
+            "evals_per_s": world * evals_per_launch / (k_ms * 1e-3),
+            "energy_checksum": float(np.sum(f)),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_lds_minimize<12>", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_eval": bytes_per_eval,
+                         "achieved_xgrouped": evals_per_launch * bytes_per_eval_grouped / (k_ms * 1e-3) / 1e9,
+                         "note": "state is LDS-resident: algorithmic bytes never reach HBM, frac may exceed 1"},
+        }
+        if heis is not None:
+            out["heis20"] = heis
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(tq, ham, psi0, batch, G, args.cpu_steps, args.maxfun)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,19 +100,31 @@ int vqe_minimize_cobyla(vqe_t* h, const double* x0, double rhobeg, double rhoend
  * Circuits are concatenated; circuit b owns gates [gate_off[b], gate_off[b+1]) and
  * parameters [par_off[b], par_off[b+1]); param_idx is local to the circuit.
  * vqe_batch_load copies the description (and x0 / theta) into device memory; the
- * *_run calls only launch device work on resident data; vqe_batch_fetch copies results
- * back.  replaces: B independent CircuitEnv.scipy_optim / get_energy calls
+ * *_run calls only launch device work on resident data and never modify it (a run can be
+ * repeated); vqe_batch_fetch copies results back.  replaces: B independent CircuitEnv.scipy_optim / get_energy calls
  * (environment_qulacs_TN_notin_agent.py:442-482). */
 int vqe_batch_load(vqe_t* h, int batch, const int64_t* gate_off, const int32_t* kind,
                    const int32_t* q0, const int32_t* q1, const int32_t* param_idx,
                    const int64_t* par_off, const double* theta0);
 int vqe_batch_run_energy(vqe_t* h);
 int vqe_batch_run_minimize(vqe_t* h, double rhobeg, double rhoend, int maxfun);
+/* One CircuitEnv.step() worth of arithmetic per circuit, in ONE launch
+ * (environment_qulacs_TN_notin_agent.py:283-291): new_gate[b] is the index, inside circuit
+ * b, of the gate the RL action just added (-1: none).  COBYLA runs on the circuit WITHOUT
+ * that gate from x0 = theta0 (the reference optimises the pre-action state, :453); the
+ * optimum is rounded to float32 (state-tensor dtype, :480) and the energy of the FULL
+ * circuit at those angles is returned in f (the extra get_energy() of :291).  x receives
+ * all n_params angles (the new rotation keeps its theta0 value), nfev COBYLA's count. */
+int vqe_batch_set_new_gate(vqe_t* h, const int32_t* new_gate /* batch, or NULL */);
+int vqe_batch_run_env_step(vqe_t* h, double rhobeg, double rhoend, int maxfun);
 int vqe_batch_fetch(vqe_t* h, double* x /* sum of n_params, may be NULL */,
                     double* f /* batch */, int32_t* nfev /* batch, may be NULL */);
 /* device pointer to the batch's f / energy array (float64[batch]) for on-device
  * reductions by the caller (e.g. torch.distributed all_reduce over RCCL) */
 int vqe_batch_energy_devptr(vqe_t* h, void** dev_ptr);
+/* asynchronous device-to-device copy of that array into caller-owned device memory
+ * (e.g. a torch tensor) on the handle's stream */
+int vqe_batch_copy_energy(vqe_t* h, void* dst_dev /* float64[batch] */);
 /* kernel time of the last *_run call measured with HIP events on the handle's stream */
 int vqe_last_kernel_ms(vqe_t* h, float* ms);
 

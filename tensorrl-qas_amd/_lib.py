@@ -34,8 +34,11 @@ SIGNATURES = {
     "vqe_batch_load": (C.c_int, [vp, C.c_int, c_i64p, c_i32p, c_i32p, c_i32p, c_i32p, c_i64p, c_f64p]),
     "vqe_batch_run_energy": (C.c_int, [vp]),
     "vqe_batch_run_minimize": (C.c_int, [vp, C.c_double, C.c_double, C.c_int]),
+    "vqe_batch_set_new_gate": (C.c_int, [vp, c_i32p]),
+    "vqe_batch_run_env_step": (C.c_int, [vp, C.c_double, C.c_double, C.c_int]),
     "vqe_batch_fetch": (C.c_int, [vp, c_f64p, c_f64p, c_i32p]),
     "vqe_batch_energy_devptr": (C.c_int, [vp, C.POINTER(vp)]),
+    "vqe_batch_copy_energy": (C.c_int, [vp, vp]),
     "vqe_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "vqe_cobyla_create": (C.c_int, [C.c_int, c_f64p, C.c_double, C.c_double, C.c_int, C.POINTER(vp)]),
     "vqe_cobyla_ask": (C.c_int, [vp, c_f64p]),

@@ -71,8 +71,10 @@ struct vqe_handle {
   std::vector<int32_t> h_par_count;
   DevBuf<GateRec> d_gates;
   DevBuf<int64_t> d_gate_begin, d_par_begin, d_scratch_begin;
-  DevBuf<int32_t> d_gate_count, d_par_count, d_nfev;
-  DevBuf<double> d_theta, d_f, d_scratch;
+  DevBuf<int32_t> d_gate_count, d_par_count, d_nfev, d_new_gate;
+  bool has_new_gate = false;
+  std::vector<int32_t> h_gate_count;
+  DevBuf<double> d_theta, d_x, d_f, d_scratch;
   DevBuf<double2> d_state;
   StreamWork sw;  // streaming-path work buffers
 };
@@ -210,7 +212,7 @@ int check_gates(vqe_t* h, int64_t n_gates, const int32_t* kind, const int32_t* q
 
 template <int N>
 int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
-  const size_t lds = lds_bytes(N, A.max_ops, A.max_params);
+  const size_t lds = lds_bytes(N, A.max_ops, A.max_params, A.ham.n_groups);
   if (lds > (size_t)h->lds_per_cu)
     return fail(h, VQE_EINVAL, "circuit too large for the LDS-resident path (gates + parameters)");
   const void* fn = which == 0 ? (const void*)k_lds_energy<N>
@@ -247,6 +249,9 @@ BatchArgs make_args(vqe_t* h) {
   A.par_begin = h->d_par_begin.p;
   A.par_count = h->d_par_count.p;
   A.theta = h->d_theta.p;
+  A.xout = h->d_x.p;
+  A.new_gate = nullptr;
+  A.env_step = 0;
   A.fout = h->d_f.p;
   A.nfev = h->d_nfev.p;
   A.scratch = h->d_scratch.p;
@@ -289,6 +294,7 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   if ((rc = upload(h, h->d_scratch_begin, sbeg.data(), sbeg.size()))) return rc;
   if ((rc = upload(h, h->d_theta, theta0, (size_t)total_params))) return rc;
   HIP_TRY(h, h->d_scratch.reserve((size_t)stot + 2));
+  HIP_TRY(h, h->d_x.reserve((size_t)total_params + 1));
   HIP_TRY(h, h->d_f.reserve(batch));
   HIP_TRY(h, h->d_nfev.reserve(batch));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -298,6 +304,8 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   h->max_params = (max_par + 3) & ~3;
   h->h_par_begin = pbeg;
   h->h_par_count = pcnt;
+  h->h_gate_count = gcnt;
+  h->has_new_gate = false;
   return VQE_OK;
 }
 
@@ -349,7 +357,8 @@ int stream_run(vqe_t* h, int which, BatchArgs& A) {
       for (int b = 0; b < B; ++b) active += vqe_cobyla_ask(cob[b], x.data() + h->h_par_begin[b]) == 1;
       if (!active) break;
       if (h->total_params)
-        HIP_TRY(h, hipMemcpyAsync(h->d_theta.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_x.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
+      A.theta = h->d_x.p;  // trial points live in the output buffer; x0 stays untouched
       rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base + (++it), true, h->err);
       if (rc) return rc;
       HIP_TRY(h, hipMemcpyAsync(f.data(), h->d_f.p, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
@@ -360,7 +369,7 @@ int stream_run(vqe_t* h, int which, BatchArgs& A) {
     std::vector<int32_t> nfev(B);
     for (int b = 0; b < B; ++b) vqe_cobyla_result(cob[b], x.data() + h->h_par_begin[b], &f[b], &nfev[b], nullptr);
     if (h->total_params)
-      HIP_TRY(h, hipMemcpyAsync(h->d_theta.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipMemcpyAsync(h->d_x.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_f.p, f.data(), (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_nfev.p, nfev.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -375,6 +384,12 @@ int run(vqe_t* h, int which, double rhobeg, double rhoend, int maxfun) {
   BatchArgs A = make_args(h);
   A.rhobeg = rhobeg; A.rhoend = rhoend; A.maxfun = maxfun;
   int rc;
+  if (which == 3) {
+    which = 1;
+    A.env_step = 1;
+    A.new_gate = h->has_new_gate ? h->d_new_gate.p : nullptr;
+    if (!h->lds_path) return fail(h, VQE_ESTATE, "the fused env-step launch serves the LDS-resident path (n <= 13)");
+  }
   if (which == 1 && h->shard_world > 1)
     return fail(h, VQE_ESTATE, "term-sharded handles hold partial energies: drive COBYLA with "
                                "vqe_cobyla_ask/tell and sum the partial energies of all ranks");
@@ -607,12 +622,33 @@ int vqe_batch_run_minimize(vqe_t* h, double rhobeg, double rhoend, int maxfun) {
   return run(h, 1, rhobeg, rhoend, maxfun);
 }
 
+int vqe_batch_set_new_gate(vqe_t* h, const int32_t* new_gate) {
+  if (!h) return VQE_EINVAL;
+  if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
+  if (!new_gate) { h->has_new_gate = false; return VQE_OK; }
+  for (int b = 0; b < h->batch; ++b)
+    if (new_gate[b] < -1 || new_gate[b] >= h->h_gate_count[b]) return fail(h, VQE_EINVAL, "new_gate index out of range");
+  HIP_TRY(h, hipSetDevice(h->dev));
+  int rc = upload(h, h->d_new_gate, new_gate, (size_t)h->batch);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->has_new_gate = true;
+  return VQE_OK;
+}
+
+int vqe_batch_run_env_step(vqe_t* h, double rhobeg, double rhoend, int maxfun) {
+  int rc = ready(h);
+  if (rc) return rc;
+  if (maxfun < 1 || !(rhobeg > 0) || !(rhoend > 0)) return fail(h, VQE_EINVAL, "bad COBYLA arguments");
+  return run(h, 3, rhobeg, rhoend, maxfun);
+}
+
 int vqe_batch_fetch(vqe_t* h, double* x, double* f, int32_t* nfev) {
   if (!h) return VQE_EINVAL;
   if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
   HIP_TRY(h, hipSetDevice(h->dev));
   if (x && h->total_params)
-    HIP_TRY(h, hipMemcpyAsync(x, h->d_theta.p, (size_t)h->total_params * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(x, h->d_x.p, (size_t)h->total_params * 8, hipMemcpyDeviceToHost, h->stream));
   if (f) HIP_TRY(h, hipMemcpyAsync(f, h->d_f.p, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
   if (nfev) HIP_TRY(h, hipMemcpyAsync(nfev, h->d_nfev.p, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -623,6 +659,14 @@ int vqe_batch_energy_devptr(vqe_t* h, void** p) {
   if (!h || !p) return VQE_EINVAL;
   if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
   *p = h->d_f.p;
+  return VQE_OK;
+}
+
+int vqe_batch_copy_energy(vqe_t* h, void* dst_dev) {
+  if (!h || !dst_dev) return VQE_EINVAL;
+  if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
+  HIP_TRY(h, hipSetDevice(h->dev));
+  HIP_TRY(h, hipMemcpyAsync(dst_dev, h->d_f.p, (size_t)h->batch * 8, hipMemcpyDeviceToDevice, h->stream));
   return VQE_OK;
 }
 

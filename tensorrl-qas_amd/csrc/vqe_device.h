@@ -56,7 +56,10 @@ struct BatchArgs {
   const int32_t* gate_count;   // [batch]
   const int64_t* par_begin;    // [batch]
   const int32_t* par_count;    // [batch]
-  double* theta;               // [sum P] in: theta / x0   out (minimize): x
+  const double* theta;         // [sum P] in: theta / x0 (never written: runs are repeatable)
+  double* xout;                // [sum P] out: optimised parameters (minimize / env_step)
+  const int32_t* new_gate;     // [batch] or NULL: index of the gate the RL action just added
+  int env_step;                // 1: after COBYLA round x to float32 and evaluate the full circuit
   double* fout;                // [batch]
   int32_t* nfev;               // [batch]
   double* scratch;             // COBYLA scratch
@@ -113,95 +116,131 @@ struct DevCtx {
 };
 
 // LDS carve-up of one workgroup.
+struct GroupMeta { uint32_t x; int32_t hb; int32_t off_r; int32_t off_i; };
+
 struct Lds {
-  double2* psi;     // [2^n]
+  double2* psi;     // [2^n]  (also: gate staging during compile, COBYLA matrices during tell)
   Op* ops;          // [max_ops]
   double2* cs;      // [max_params] (cos, sin)(theta/2)
+  GroupMeta* gm;    // [n_groups]
   double* red;      // [8]
   uint32_t* xm;     // [32] columns of A^-1
+  uint32_t* zm;     // [32] rows of A
   int32_t* meta;    // [8]: n_ops, offset c, phase power, permuted flag
 };
 
-__host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params) {
-  return ((size_t)16 << n) + (size_t)16 * max_ops + (size_t)16 * max_params + 64 + 128 + 32;
+__host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params, int n_groups) {
+  return ((size_t)16 << n) + (size_t)16 * max_ops + (size_t)16 * max_params +
+         (size_t)16 * (n_groups > 0 ? n_groups : 1) + 64 + 128 + 128 + 32;
 }
 
-__device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, int max_params) {
+__device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, int max_params, int n_groups) {
   Lds l;
   l.psi = (double2*)base; base += (size_t)16 << n;
   l.ops = (Op*)base; base += (size_t)16 * max_ops;
   l.cs = (double2*)base; base += (size_t)16 * max_params;
+  l.gm = (GroupMeta*)base; base += (size_t)16 * (n_groups > 0 ? n_groups : 1);
   l.red = (double*)base; base += 64;
   l.xm = (uint32_t*)base; base += 128;
+  l.zm = (uint32_t*)base; base += 128;
   l.meta = (int32_t*)base;
   return l;
 }
 
-// Thread 0: translate the gate list of problem b into pair-exchange ops (CNOT / Pauli-X
-// become updates of the affine map).  Noise Paulis are drawn per evaluation.
-__device__ inline void compile_ops(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L) {
-  const int n = A.n;
-  uint32_t xm[32], zm[32];
-  for (int q = 0; q < n; ++q) { xm[q] = 1u << q; zm[q] = 1u << q; }
-  uint32_t c = 0;
-  int phase = 0, nops = 0;
-  const GateRec* g = A.gates + A.gate_begin[b];
-  const int G = A.gate_count[b];
-  auto pauli = [&](int q, int p) {  // 1=X 2=Y 3=Z on logical qubit q
-    if (p == 0) return;
-    if (p == 1 || p == 2) c ^= 1u << q;
-    if (p == 2 || p == 3) {
-      if (nops < A.max_ops) L.ops[nops] = Op{0u, zm[q], -1, OP_PZ | (int)(((c >> q) & 1u) << 8)};
-      ++nops;
-    }
-    if (p == 2) phase = (phase + 3) & 3;
-  };
-  for (int i = 0; i < G; ++i) {
-    const GateRec r = g[i];
-    switch (r.kind) {
-      case G_CNOT:
-        zm[r.q1] ^= zm[r.q0];
-        xm[r.q0] ^= xm[r.q1];
-        if ((c >> r.q0) & 1u) c ^= 1u << r.q1;
-        break;
-      case G_RX: case G_RY: case G_RZ:
-        if (nops < A.max_ops)
-          L.ops[nops] = Op{xm[r.q0], zm[r.q0], r.pidx, r.kind | (int)(((c >> r.q0) & 1u) << 8)};
-        ++nops;
-        break;
-      case G_DEPOL1: {
-        const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
-        if (u < A.noise.p1) pauli(r.q0, 1 + (int)(u / A.noise.p1 * 3.0));
-        break;
-      }
-      case G_DEPOL2: {
-        const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
-        if (u < A.noise.p2) {
-          const int idx = 1 + (int)(u / A.noise.p2 * 15.0);
-          pauli(r.q0, idx & 3);
-          pauli(r.q1, idx >> 2);
-        }
-        break;
-      }
-      default: break;
-    }
+// Once per kernel: X-mask group descriptors into LDS (no dependent global loads later).
+__device__ inline void stage_groups(const HamDev& H, const Lds& L) {
+  for (int g = threadIdx.x; g < H.n_groups; g += kThreads) {
+    const uint32_t x = H.gx[g];
+    L.gm[g] = GroupMeta{x, x ? 31 - __clz((int)x) : 0, (int32_t)H.tab_r[g], (int32_t)H.tab_i[g]};
   }
-  int permuted = (c != 0);
-  for (int q = 0; q < n; ++q) { L.xm[q] = xm[q]; if (xm[q] != (1u << q)) permuted = 1; }
-  L.meta[0] = nops < A.max_ops ? nops : A.max_ops;
-  L.meta[1] = (int32_t)c;
-  L.meta[2] = phase;
-  L.meta[3] = permuted;
+}
+
+// Translate the gate list of problem b into pair-exchange ops (CNOT / Pauli-X become
+// updates of the affine map).  All threads stage the gate records into the (idle) state
+// region, thread 0 walks them.  Noise Paulis are drawn per evaluation.  Ends with a barrier.
+__device__ inline void compile_ops(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip = -1) {
+  const int n = A.n;
+  const int G = A.gate_count[b];
+  const int cap = (int)(((size_t)16 << n) / sizeof(GateRec));
+  const GateRec* gsrc = A.gates + A.gate_begin[b];
+  GateRec* gl = (GateRec*)L.psi;
+  const bool staged = G <= cap;
+  if (staged) {
+    const int4* s4 = (const int4*)gsrc;
+    int4* d4 = (int4*)gl;
+    for (int i = threadIdx.x; i < G; i += kThreads) d4[i] = s4[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const GateRec* g = staged ? gl : gsrc;
+    uint32_t* xm = L.xm;
+    uint32_t* zm = L.zm;
+    for (int q = 0; q < n; ++q) { xm[q] = 1u << q; zm[q] = 1u << q; }
+    uint32_t c = 0;
+    int phase = 0, nops = 0;
+    auto pauli = [&](int q, int p) {  // 1=X 2=Y 3=Z on logical qubit q
+      if (p == 0) return;
+      if (p == 1 || p == 2) c ^= 1u << q;
+      if (p == 2 || p == 3) {
+        if (nops < A.max_ops) L.ops[nops] = Op{0u, zm[q], -1, OP_PZ | (int)(((c >> q) & 1u) << 8)};
+        ++nops;
+      }
+      if (p == 2) phase = (phase + 3) & 3;
+    };
+    for (int i = 0; i < G; ++i) {
+      if (i == skip) continue;
+      const GateRec r = g[i];
+      switch (r.kind) {
+        case G_CNOT:
+          zm[r.q1] ^= zm[r.q0];
+          xm[r.q0] ^= xm[r.q1];
+          if ((c >> r.q0) & 1u) c ^= 1u << r.q1;
+          break;
+        case G_RX: case G_RY: case G_RZ:
+          if (nops < A.max_ops)
+            L.ops[nops] = Op{xm[r.q0], zm[r.q0], r.pidx, r.kind | (int)(((c >> r.q0) & 1u) << 8)};
+          ++nops;
+          break;
+        case G_DEPOL1: {
+          const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
+          if (u < A.noise.p1) pauli(r.q0, 1 + (int)(u / A.noise.p1 * 3.0));
+          break;
+        }
+        case G_DEPOL2: {
+          const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
+          if (u < A.noise.p2) {
+            const int idx = 1 + (int)(u / A.noise.p2 * 15.0);
+            pauli(r.q0, idx & 3);
+            pauli(r.q1, idx >> 2);
+          }
+          break;
+        }
+        default: break;
+      }
+    }
+    int permuted = (c != 0);
+    for (int q = 0; q < n; ++q) if (xm[q] != (1u << q)) permuted = 1;
+    L.meta[0] = nops < A.max_ops ? nops : A.max_ops;
+    L.meta[1] = (int32_t)c;
+    L.meta[2] = phase;
+    L.meta[3] = permuted;
+  }
+  __syncthreads();
 }
 
 // Apply the compiled ops to the LDS-resident state, then restore the logical layout.
+// `theta` holds the P parameters of the circuit, or - when p_hole >= 0 - the P-1 parameters
+// of the circuit without the rotation whose parameter index is p_hole.
 template <int N>
-__device__ inline void run_ops(const Lds& L, const double* theta, int P) {
+__device__ inline void run_ops(const Lds& L, const double* theta, int P, int p_hole = -1) {
   constexpr uint32_t DIM = 1u << N;
+  constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;   // pairs per thread
+  constexpr int NA = (DIM + kThreads - 1) / kThreads;       // amplitudes per thread
   const int tid = threadIdx.x;
   for (int j = tid; j < P; j += kThreads) {
+    if (j == p_hole) continue;
     double s, c;
-    sincos(0.5 * theta[j], &s, &c);
+    sincos(0.5 * theta[j - (p_hole >= 0 && j > p_hole)], &s, &c);
     L.cs[j] = make_double2(c, s);
   }
   __syncthreads();
@@ -214,45 +253,59 @@ __device__ inline void run_ops(const Lds& L, const double* theta, int P) {
       const double2 cs = L.cs[op.pidx];
       const int hb = 31 - __clz((int)op.xm);
       if (kind == OP_RX) {
-        for (uint32_t q = tid; q < DIM / 2; q += kThreads) {
-          const uint32_t p0 = insert0(q, hb), p1 = p0 ^ op.xm;
-          const double2 a0 = L.psi[p0], a1 = L.psi[p1];
-          L.psi[p0] = make_double2(cs.x * a0.x - cs.y * a1.y, cs.x * a0.y + cs.y * a1.x);
-          L.psi[p1] = make_double2(cs.x * a1.x - cs.y * a0.y, cs.x * a1.y + cs.y * a0.x);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const uint32_t q = tid + k * kThreads;
+          if (DIM / 2 >= kThreads || q < DIM / 2) {
+            const uint32_t p0 = insert0(q, hb), p1 = p0 ^ op.xm;
+            const double2 a0 = L.psi[p0], a1 = L.psi[p1];
+            L.psi[p0] = make_double2(cs.x * a0.x - cs.y * a1.y, cs.x * a0.y + cs.y * a1.x);
+            L.psi[p1] = make_double2(cs.x * a1.x - cs.y * a0.y, cs.x * a1.y + cs.y * a0.x);
+          }
         }
       } else {
-        for (uint32_t q = tid; q < DIM / 2; q += kThreads) {
-          const uint32_t p0 = insert0(q, hb), p1 = p0 ^ op.xm;
-          const double s0 = (parity32(p0 & op.zm) ^ inv) ? -cs.y : cs.y;
-          const double2 a0 = L.psi[p0], a1 = L.psi[p1];
-          L.psi[p0] = make_double2(cs.x * a0.x + s0 * a1.x, cs.x * a0.y + s0 * a1.y);
-          L.psi[p1] = make_double2(cs.x * a1.x - s0 * a0.x, cs.x * a1.y - s0 * a0.y);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const uint32_t q = tid + k * kThreads;
+          if (DIM / 2 >= kThreads || q < DIM / 2) {
+            const uint32_t p0 = insert0(q, hb), p1 = p0 ^ op.xm;
+            const double s0 = (parity32(p0 & op.zm) ^ inv) ? -cs.y : cs.y;
+            const double2 a0 = L.psi[p0], a1 = L.psi[p1];
+            L.psi[p0] = make_double2(cs.x * a0.x + s0 * a1.x, cs.x * a0.y + s0 * a1.y);
+            L.psi[p1] = make_double2(cs.x * a1.x - s0 * a0.x, cs.x * a1.y - s0 * a0.y);
+          }
         }
       }
     } else if (kind == OP_RZ) {
       const double2 cs = L.cs[op.pidx];
-      for (uint32_t p = tid; p < DIM; p += kThreads) {
-        const double s = (parity32(p & op.zm) ^ inv) ? -cs.y : cs.y;
-        const double2 a = L.psi[p];
-        L.psi[p] = make_double2(cs.x * a.x - s * a.y, cs.x * a.y + s * a.x);
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const uint32_t p = tid + k * kThreads;
+        if (DIM >= kThreads || p < DIM) {
+          const double s = (parity32(p & op.zm) ^ inv) ? -cs.y : cs.y;
+          const double2 a = L.psi[p];
+          L.psi[p] = make_double2(cs.x * a.x - s * a.y, cs.x * a.y + s * a.x);
+        }
       }
     } else {  // OP_PZ
-      for (uint32_t p = tid; p < DIM; p += kThreads)
-        if (parity32(p & op.zm) ^ inv) {
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const uint32_t p = tid + k * kThreads;
+        if ((DIM >= kThreads || p < DIM) && (parity32(p & op.zm) ^ inv)) {
           const double2 a = L.psi[p];
           L.psi[p] = make_double2(-a.x, -a.y);
         }
+      }
     }
     __syncthreads();
   }
   if (L.meta[3]) {  // psi_logical[i] = phi[A^-1 (i ^ c)]
-    constexpr int APT = (DIM + kThreads - 1) / kThreads;
     const uint32_t c = (uint32_t)L.meta[1];
-    double2 tmp[APT];
+    double2 tmp[NA];
 #pragma unroll
-    for (int k = 0; k < APT; ++k) {
+    for (int k = 0; k < NA; ++k) {
       const uint32_t i = tid + k * kThreads;
-      if (i < DIM) {
+      if (DIM >= kThreads || i < DIM) {
         uint32_t v = i ^ c, p = 0;
 #pragma unroll
         for (int q = 0; q < N; ++q) p ^= ((v >> q) & 1u) ? L.xm[q] : 0u;
@@ -261,9 +314,9 @@ __device__ inline void run_ops(const Lds& L, const double* theta, int P) {
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < APT; ++k) {
+    for (int k = 0; k < NA; ++k) {
       const uint32_t i = tid + k * kThreads;
-      if (i < DIM) L.psi[i] = tmp[k];
+      if (DIM >= kThreads || i < DIM) L.psi[i] = tmp[k];
     }
     __syncthreads();
   }
@@ -272,69 +325,151 @@ __device__ inline void run_ops(const Lds& L, const double* theta, int P) {
 template <int N>
 __device__ inline void load_init(const Lds& L, const double2* init) {
   constexpr uint32_t DIM = 1u << N;
-  for (uint32_t p = threadIdx.x; p < DIM; p += kThreads) L.psi[p] = init[p];
+  constexpr int NA = (DIM + kThreads - 1) / kThreads;
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    const uint32_t p = threadIdx.x + k * kThreads;
+    if (DIM >= kThreads || p < DIM) L.psi[p] = init[p];
+  }
 }
 
 // <psi|H|psi> over this handle's X-mask groups; identical result in every thread.
+// Sign-sum tables stream from L2 one group ahead of the LDS pair reads that consume them.
 template <int N>
 __device__ inline double lds_energy(const Lds& L, const HamDev& H) {
   constexpr uint32_t DIM = 1u << N;
+  constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;
   const int tid = threadIdx.x;
+  const double* __restrict__ tables = H.tables;
   double acc = 0.0;
-  for (int g = 0; g < H.n_groups; ++g) {
-    const uint32_t x = H.gx[g];
-    const double* __restrict__ tr = H.tables + H.tab_r[g];
-    const int64_t oi = H.tab_i[g];
-    if (x == 0) {
-      for (uint32_t p = tid; p < DIM; p += kThreads) {
-        const double2 a = L.psi[p];
-        acc += (a.x * a.x + a.y * a.y) * tr[p];
+  const int ng = H.n_groups;
+  double cur[NP], nxt[NP];
+  auto fetch = [&](int g, double* dst) {
+    const GroupMeta m = L.gm[g];
+    const double* t = tables + m.off_r;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const uint32_t q = tid + k * kThreads;
+      dst[k] = (DIM / 2 >= kThreads || q < DIM / 2) ? t[q] : 0.0;
+    }
+  };
+  if (ng > 0) fetch(0, cur);
+  for (int g = 0; g < ng; ++g) {
+    const GroupMeta m = L.gm[g];
+    if (g + 1 < ng) fetch(g + 1, nxt);
+    if (m.x == 0) {
+      // diagonal group: full-length table; second half fetched here
+      const double* t = tables + m.off_r;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const uint32_t p = tid + k * kThreads;
+        if (DIM / 2 >= kThreads || p < DIM / 2) {
+          const double2 a = L.psi[p];
+          acc += (a.x * a.x + a.y * a.y) * cur[k];
+          const uint32_t p2 = p + DIM / 2;
+          const double2 a2 = L.psi[p2];
+          acc += (a2.x * a2.x + a2.y * a2.y) * t[p2];
+        }
       }
     } else {
-      const int hb = 31 - __clz((int)x);
-      if (oi < 0) {
-        double part = 0.0;
-        for (uint32_t q = tid; q < DIM / 2; q += kThreads) {
-          const uint32_t p0 = insert0(q, hb);
-          const double2 b = L.psi[p0], a = L.psi[p0 ^ x];
-          part += (a.x * b.x + a.y * b.y) * tr[q];
+      double part = 0.0;
+      if (m.off_i < 0) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const uint32_t q = tid + k * kThreads;
+          if (DIM / 2 >= kThreads || q < DIM / 2) {
+            const uint32_t p0 = insert0(q, m.hb);
+            const double2 b = L.psi[p0], a = L.psi[p0 ^ m.x];
+            part += (a.x * b.x + a.y * b.y) * cur[k];
+          }
         }
-        acc += 2.0 * part;
       } else {
-        const double* __restrict__ ti = H.tables + oi;
-        double part = 0.0;
-        for (uint32_t q = tid; q < DIM / 2; q += kThreads) {
-          const uint32_t p0 = insert0(q, hb);
-          const double2 b = L.psi[p0], a = L.psi[p0 ^ x];
-          part += (a.x * b.x + a.y * b.y) * tr[q] - (a.x * b.y - a.y * b.x) * ti[q];
+        const double* ti = tables + m.off_i;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const uint32_t q = tid + k * kThreads;
+          if (DIM / 2 >= kThreads || q < DIM / 2) {
+            const uint32_t p0 = insert0(q, m.hb);
+            const double2 b = L.psi[p0], a = L.psi[p0 ^ m.x];
+            part += (a.x * b.x + a.y * b.y) * cur[k] - (a.x * b.y - a.y * b.x) * ti[q];
+          }
         }
-        acc += 2.0 * part;
       }
+      acc += 2.0 * part;
     }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) cur[k] = nxt[k];
   }
   return block_sum(acc, L.red);
 }
 
 template <int N>
 __device__ inline double lds_evaluate(const BatchArgs& A, int b, const Lds& L, const double* theta,
-                                      int P, bool noisy, uint64_t eval_id) {
-  if (noisy) {
-    if (threadIdx.x == 0) compile_ops(A, b, eval_id, L);
-  }
+                                      int P, bool noisy, uint64_t eval_id, int skip = -1, int p_hole = -1) {
+  if (noisy) compile_ops(A, b, eval_id, L, skip);
   load_init<N>(L, A.init);
   __syncthreads();
-  run_ops<N>(L, theta, P);
+  run_ops<N>(L, theta, P, p_hole);
   return lds_energy<N>(L, A.ham);
 }
+
+// COBYLA with its matrices staged into the state region of LDS while the state is dead
+// (between two evaluations); falls back to the global scratch when they do not fit.
+template <int N>
+struct StagedCobyla {
+  cby::CobylaM0<DevCtx> cob;
+  double* gmem;
+  double* lmem;
+  int words;
+  bool staged;
+  __device__ void init(double* global_scratch, const Lds& L, int n) {
+    gmem = global_scratch;
+    lmem = (double*)L.psi;
+    words = (int)cby::scratch_doubles(n);
+    staged = (size_t)words * 8 <= ((size_t)16 << N);
+    cob.ctx.tid = threadIdx.x;
+    cob.bind(gmem, n);
+  }
+  __device__ void in() {
+    if (!staged) return;
+    const double2* s = (const double2*)gmem;
+    double2* d = (double2*)lmem;
+    for (int i = threadIdx.x; i < (words + 1) / 2; i += kThreads) d[i] = s[i];
+    cob.bind(lmem, cob.n);
+    __syncthreads();
+  }
+  __device__ void out() {
+    if (!staged) return;
+    __syncthreads();
+    const double2* s = (const double2*)lmem;
+    double2* d = (double2*)gmem;
+    for (int i = threadIdx.x; i < (words + 1) / 2; i += kThreads) d[i] = s[i];
+    cob.bind(gmem, cob.n);
+    __syncthreads();
+  }
+  __device__ int start(double rhobeg, double rhoend, int maxfun) {
+    in();
+    const int w = cob.start(rhobeg, rhoend, maxfun);
+    out();
+    return w;
+  }
+  __device__ int tell(double f) {
+    in();
+    const int w = cob.tell(f);
+    out();
+    return w;
+  }
+};
 
 // ---- kernels -----------------------------------------------------------------------------
 template <int N>
 __global__ void __launch_bounds__(kThreads) k_lds_energy(BatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds L = carve(smem, N, A.max_ops, A.max_params);
+  const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
   const int b = blockIdx.x;
   const bool noisy = (A.noise.p1 > 0.0 || A.noise.p2 > 0.0);
-  if (!noisy && threadIdx.x == 0) compile_ops(A, b, 0, L);
+  stage_groups(A.ham, L);
+  if (!noisy) compile_ops(A, b, 0, L);
   __syncthreads();
   const double e = lds_evaluate<N>(A, b, L, A.theta + A.par_begin[b], A.par_count[b], noisy,
                                    A.noise.eval_base);
@@ -344,8 +479,8 @@ __global__ void __launch_bounds__(kThreads) k_lds_energy(BatchArgs A) {
 template <int N>
 __global__ void __launch_bounds__(kThreads) k_lds_state(BatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds L = carve(smem, N, A.max_ops, A.max_params);
-  if (threadIdx.x == 0) compile_ops(A, 0, A.noise.eval_base, L);
+  const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
+  compile_ops(A, 0, A.noise.eval_base, L);
   load_init<N>(L, A.init);
   __syncthreads();
   run_ops<N>(L, A.theta + A.par_begin[0], A.par_count[0]);
@@ -360,37 +495,65 @@ __global__ void __launch_bounds__(kThreads) k_lds_state(BatchArgs A) {
 }
 
 // Whole inner VQE loop of one environment in one workgroup.
+//
+// Plain mode: minimise E(theta) of circuit b from x0 = theta.
+// With new_gate[b] = g >= 0 the loop follows CircuitEnv.step of the reference
+// (environments/environment_qulacs_TN_notin_agent.py:283-291,452-482): COBYLA optimises the
+// circuit WITHOUT gate g (the action just taken; its angle, if it is a rotation, is not a
+// variable), and with env_step = 1 the optimum is rounded to float32 (the state tensor's
+// dtype, :480) and the energy of the FULL circuit is reported (:291).
 template <int N>
 __global__ void __launch_bounds__(kThreads) k_lds_minimize(BatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds L = carve(smem, N, A.max_ops, A.max_params);
+  const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
   const int b = blockIdx.x;
   const int P = A.par_count[b];
-  double* theta = A.theta + A.par_begin[b];
+  const double* theta = A.theta + A.par_begin[b];
+  double* xout = A.xout + A.par_begin[b];
   const bool noisy = (A.noise.p1 > 0.0 || A.noise.p2 > 0.0);
-  if (!noisy && threadIdx.x == 0) compile_ops(A, b, 0, L);
+  const int skip = A.new_gate ? A.new_gate[b] : -1;
+  int p_hole = -1;
+  if (skip >= 0) {
+    const GateRec r = A.gates[A.gate_begin[b] + skip];
+    if (r.kind >= G_RX && r.kind <= G_RZ) p_hole = r.pidx;
+  }
+  const int Popt = P - (p_hole >= 0);
+  stage_groups(A.ham, L);
+  if (!noisy) compile_ops(A, b, 0, L, skip);
   __syncthreads();
-  if (P == 0) {  // scipy returns after a single evaluation for an empty x0
-    const double e = lds_evaluate<N>(A, b, L, theta, 0, noisy, A.noise.eval_base);
-    if (threadIdx.x == 0) { A.fout[b] = e; A.nfev[b] = 1; }
-    return;
+  int nfev = 1;
+  double fret;
+  if (Popt == 0) {  // scipy returns after a single evaluation for an empty x0
+    fret = lds_evaluate<N>(A, b, L, theta, P, noisy, A.noise.eval_base, skip, p_hole);
+    for (int j = threadIdx.x; j < P; j += kThreads) xout[j] = theta[j];
+  } else {
+    StagedCobyla<N> sc;
+    sc.init(A.scratch + A.scratch_begin[b], L, Popt);
+    cby::CobylaM0<DevCtx>& cob = sc.cob;
+    for (int j = threadIdx.x; j < P; j += kThreads)
+      if (j != p_hole) cob.x[j - (p_hole >= 0 && j > p_hole)] = theta[j];
+    __syncthreads();
+    int want = sc.start(A.rhobeg, A.rhoend, A.maxfun);
+    double flast = 0.0;
+    while (want) {
+      flast = lds_evaluate<N>(A, b, L, cob.x, P, noisy, A.noise.eval_base + (uint64_t)cob.nfvals, skip, p_hole);
+      want = sc.tell(flast);
+    }
+    for (int j = threadIdx.x; j < P; j += kThreads) {
+      const double v = (j == p_hole) ? theta[j] : cob.x[j - (p_hole >= 0 && j > p_hole)];
+      xout[j] = A.env_step ? (double)(float)v : v;
+    }
+    fret = (cob.status == cby::DONE_RHOEND && cob.ifull == 1) ? flast : cob.fbest_ret;
+    nfev = cob.nfvals;
   }
-  cby::CobylaM0<DevCtx> cob;
-  cob.ctx.tid = threadIdx.x;
-  cob.bind(A.scratch + A.scratch_begin[b], P);
-  for (int i = threadIdx.x; i < P; i += kThreads) cob.x[i] = theta[i];
-  __syncthreads();
-  int want = cob.start(A.rhobeg, A.rhoend, A.maxfun);
-  double flast = 0.0;
-  while (want) {
-    flast = lds_evaluate<N>(A, b, L, cob.x, P, noisy, A.noise.eval_base + (uint64_t)cob.nfvals);
-    want = cob.tell(flast);
+  if (A.env_step) {
+    __syncthreads();
+    if (Popt == 0)
+      for (int j = threadIdx.x; j < P; j += kThreads) xout[j] = (double)(float)theta[j];
+    if (!noisy) compile_ops(A, b, 0, L, -1);
+    fret = lds_evaluate<N>(A, b, L, xout, P, noisy, A.noise.eval_base + (uint64_t)A.maxfun + 1, -1, -1);
   }
-  for (int i = threadIdx.x; i < P; i += kThreads) theta[i] = cob.x[i];
-  if (threadIdx.x == 0) {
-    A.fout[b] = (cob.status == cby::DONE_RHOEND && cob.ifull == 1) ? flast : cob.fbest_ret;
-    A.nfev[b] = cob.nfvals;
-  }
+  if (threadIdx.x == 0) { A.fout[b] = fret; A.nfev[b] = nfev; }
 }
 
 }  // namespace vqe

@@ -180,6 +180,18 @@ class VQEEngine:
     def batch_run_minimize(self, rhobeg=1.0, rhoend=1e-4, maxfun=1000):
         self._chk(self._lib.vqe_batch_run_minimize(self._h, rhobeg, rhoend, int(maxfun)))
 
+    def batch_set_new_gate(self, new_gate):
+        if new_gate is None:
+            self._chk(self._lib.vqe_batch_set_new_gate(self._h, C.cast(None, c_i32p)))
+            return
+        ng = _i32(new_gate)
+        if ng.size != self._batch:
+            raise ValueError("new_gate needs one entry per circuit")
+        self._chk(self._lib.vqe_batch_set_new_gate(self._h, _p(ng, c_i32p)))
+
+    def batch_run_env_step(self, rhobeg=1.0, rhoend=1e-4, maxfun=1000):
+        self._chk(self._lib.vqe_batch_run_env_step(self._h, rhobeg, rhoend, int(maxfun)))
+
     def batch_fetch(self, want_x=True):
         x = np.empty(self._total_params, np.float64) if want_x else None
         f = np.empty(self._batch, np.float64)
@@ -192,6 +204,9 @@ class VQEEngine:
         p = C.c_void_p()
         self._chk(self._lib.vqe_batch_energy_devptr(self._h, C.byref(p)))
         return int(p.value)
+
+    def batch_copy_energy(self, dst_dev_ptr: int):
+        self._chk(self._lib.vqe_batch_copy_energy(self._h, C.c_void_p(int(dst_dev_ptr))))
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

@@ -221,3 +221,70 @@ def test_errors(tq):
         eng.energy(np.zeros(0))                                   # no Hamiltonian yet
     with pytest.raises(tq.VQEError):
         tq.VQEEngine(40)
+
+
+def test_env_step_semantics(tq):
+    """Fused env-step launch vs the reference's step() arithmetic restated on the CPU
+    (environment_qulacs_TN_notin_agent.py:283-291,452-482): COBYLA on the circuit WITHOUT the
+    new gate, float32 round-trip of the angles, energy of the full circuit."""
+    from scipy.optimize import minimize
+    n = 8
+    rng = np.random.default_rng(11)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 60, rng)
+    eng = _engine(tq, n, psi0, ham)
+    raw, circs, ths, new = [], [], [], []
+    for b in range(8):
+        g = list(random_gates(n, 14 + b, rng, p_cnot=0.4))
+        g[4] = g[4].astype(np.float32).astype(np.float64)
+        G = g[0].size
+        ng = [G - 1, 0, G // 2, -1, G - 1, 3, G - 2, 1][b]
+        if ng >= 0 and g[0][ng] != 0:
+            g[4][g[3][ng]] = 0.0          # a new rotation enters with theta = 0
+        raw.append(g), new.append(ng)
+        circs.append(tq.Circuit(*g[:4], g[4].size)), ths.append(g[4])
+    eng.batch_load(circs, ths)
+    eng.batch_set_new_gate(new)
+    eng.batch_run_env_step(1.0, 1e-4, 1000)
+    x, f, nfev = eng.batch_fetch()
+    # repeatable: inputs are not modified by a run
+    eng.batch_run_env_step(1.0, 1e-4, 1000)
+    x2, f2, nfev2 = eng.batch_fetch()
+    assert np.array_equal(x, x2) and np.array_equal(f, f2) and np.array_equal(nfev, nfev2)
+    off = 0
+    for b, (g, ng) in enumerate(zip(raw, new)):
+        kind, q0, q1, pidx, th = g
+        P = th.size
+        xb = x[off:off + P]
+        off += P
+        assert np.array_equal(xb, xb.astype(np.float32).astype(np.float64))
+        assert abs(vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, xb), *ham) - f[b]) < E_TOL
+        keep = np.ones(kind.size, bool)
+        hole = -1
+        if ng >= 0:
+            keep[ng] = False
+            if kind[ng] != 0:
+                hole = int(pidx[ng])
+                assert xb[hole] == th[hole]
+        sel = [j for j in range(P) if j != hole]
+        pre_pidx = pidx.copy()
+        if hole >= 0:
+            pre_pidx = np.where(pidx > hole, pidx - 1, pidx)
+        cost = lambda t: vo.energy_pauli(vo.run_circuit(psi0, kind[keep], q0[keep], q1[keep], pre_pidx[keep], t), *ham)
+        if not sel:
+            assert nfev[b] == 1
+            continue
+        # (a) the optimiser made progress and stopped at a point COBYLA itself cannot improve
+        c_dev = cost(xb[sel])
+        assert c_dev <= cost(th[sel]) + 1e-12
+        polish = minimize(cost, xb[sel], method="COBYLA", options={"maxiter": 1000, "rhobeg": 1e-3})
+        assert polish.fun >= c_dev - 1e-5, (b, c_dev, polish.fun)
+        # (b) against scipy from the same start: trajectories are chaotic w.r.t. 1e-13 cost
+        # differences and the landscape has several minima, so compare energies only when both
+        # runs ended in the same basin
+        r = minimize(cost, th[sel], method="COBYLA", options={"maxiter": 1000})
+        if np.abs(r.x - xb[sel]).max() < 1e-2:
+            full = th.copy()
+            full[sel] = r.x.astype(np.float32)
+            e_ref = vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, full), *ham)
+            assert abs(f[b] - e_ref) < 1e-3, (b, f[b], e_ref, nfev[b], r.nfev)  # optimiser tolerance (rhoend is a step size)
