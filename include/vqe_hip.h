@@ -74,6 +74,9 @@ int vqe_set_hamiltonian_pauli(vqe_t* h, int n_terms, const uint64_t* xmask,
 /* Evaluate only the X-mask groups owned by `rank` of `world` (Pauli-term sharding; the
  * caller sums the partial energies of all ranks, e.g. one RCCL all-reduce). */
 int vqe_set_term_shard(vqe_t* h, int rank, int world);
+/* host only: the rank that vqe_set_term_shard(.., world) makes responsible for each term
+ * (terms sharing an X mask stay together); needs no device */
+int vqe_term_owner(int n_qubits, int n_terms, const uint64_t* xmask, int world, int32_t* owner);
 /* Stochastic Pauli noise (qulacs DepolarizingNoise / TwoQubitDepolarizingNoise
  * semantics: each non-identity Pauli with probability p/3 resp. p/15, one trajectory per
  * evaluation).  The draw for (stream, evaluation, gate) is a pure function of `seed`. */
@@ -119,6 +122,9 @@ int vqe_batch_set_new_gate(vqe_t* h, const int32_t* new_gate /* batch, or NULL *
 int vqe_batch_run_env_step(vqe_t* h, double rhobeg, double rhoend, int maxfun);
 int vqe_batch_fetch(vqe_t* h, double* x /* sum of n_params, may be NULL */,
                     double* f /* batch */, int32_t* nfev /* batch, may be NULL */);
+/* the optimiser's result before the float32 rounding of vqe_batch_run_env_step
+ * (scipy's result.x, stored by the reference as env.opt_ang_save, :288); same layout as x */
+int vqe_batch_fetch_xopt(vqe_t* h, double* x /* sum of n_params */);
 /* device pointer to the batch's f / energy array (float64[batch]) for on-device
  * reductions by the caller (e.g. torch.distributed all_reduce over RCCL) */
 int vqe_batch_energy_devptr(vqe_t* h, void** dev_ptr);

@@ -8,7 +8,7 @@ import numpy as np
 from .engine import (Circuit, GATE_CNOT, GATE_DEPOL1, GATE_DEPOL2, GATE_RX)
 
 
-def circuit_from_state(state, n_qubits, noise=False):
+def circuit_from_state(state, n_qubits, noise=False, with_layers=False):
     """``state``: (L, n+6, n) tensor/array.  Per layer: CNOTs in row-major order of
     [target][control] == 1, then rotations in row-major order of [axis][qubit] == 1.
     Parameter j is the j-th rotation met, so parameters are ordered (layer, axis, qubit) -
@@ -17,24 +17,25 @@ def circuit_from_state(state, n_qubits, noise=False):
     Returns (Circuit, angles float64[P] read from rows n+3..n+5)."""
     s = state.detach().cpu().numpy() if hasattr(state, "detach") else np.asarray(state)
     n = n_qubits
-    kind, q0, q1, pidx, ang = [], [], [], [], []
+    kind, q0, q1, pidx, ang, lay = [], [], [], [], [], []
     cn_l, cn_t, cn_c = np.nonzero(s[:, :n, :] == 1)
     ro_l, ro_a, ro_q = np.nonzero(s[:, n:n + 3, :] == 1)
     ci = ri = 0
     for layer in np.union1d(cn_l, ro_l):
         while ci < cn_l.size and cn_l[ci] == layer:
-            kind.append(GATE_CNOT), q0.append(cn_c[ci]), q1.append(cn_t[ci]), pidx.append(-1)
+            kind.append(GATE_CNOT), q0.append(cn_c[ci]), q1.append(cn_t[ci]), pidx.append(-1), lay.append(layer)
             if noise:
-                kind.append(GATE_DEPOL2), q0.append(cn_c[ci]), q1.append(cn_t[ci]), pidx.append(-1)
+                kind.append(GATE_DEPOL2), q0.append(cn_c[ci]), q1.append(cn_t[ci]), pidx.append(-1), lay.append(layer)
             ci += 1
         while ri < ro_l.size and ro_l[ri] == layer:
             a, q = int(ro_a[ri]), int(ro_q[ri])
-            kind.append(GATE_RX + a), q0.append(q), q1.append(-1), pidx.append(len(ang))
+            kind.append(GATE_RX + a), q0.append(q), q1.append(-1), pidx.append(len(ang)), lay.append(layer)
             ang.append(float(s[layer, n + 3 + a, q]))
             if noise:
-                kind.append(GATE_DEPOL1), q0.append(q), q1.append(-1), pidx.append(-1)
+                kind.append(GATE_DEPOL1), q0.append(q), q1.append(-1), pidx.append(-1), lay.append(layer)
             ri += 1
-    return Circuit(kind, q0, q1, pidx, len(ang)), np.asarray(ang, dtype=np.float64)
+    out = (Circuit(kind, q0, q1, pidx, len(ang)), np.asarray(ang, dtype=np.float64))
+    return out + (np.asarray(lay, dtype=np.int64),) if with_layers else out
 
 
 def circuit_from_qasm_gates(gates):

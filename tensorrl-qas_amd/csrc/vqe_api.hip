@@ -74,7 +74,7 @@ struct vqe_handle {
   DevBuf<int32_t> d_gate_count, d_par_count, d_nfev, d_new_gate;
   bool has_new_gate = false;
   std::vector<int32_t> h_gate_count;
-  DevBuf<double> d_theta, d_x, d_f, d_scratch;
+  DevBuf<double> d_theta, d_x, d_xraw, d_f, d_scratch;
   DevBuf<double2> d_state;
   StreamWork sw;  // streaming-path work buffers
 };
@@ -100,26 +100,35 @@ int upload(vqe_t* h, DevBuf<T>& b, const T* src, size_t n) {
   return VQE_OK;
 }
 
+// Pauli-term sharding: greedy bin packing of X-mask groups over ranks by cost (table length
+// on the LDS path, partner sweep + terms on the streaming path); deterministic, so every
+// rank computes the same partition.
+std::vector<int> assign_groups(const std::vector<uint32_t>& gx, const std::vector<std::vector<int>>& terms,
+                               bool lds_path, int world) {
+  std::vector<int> order(gx.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  auto cost = [&](int g) -> double {
+    return lds_path ? (gx[g] == 0 ? 2.0 : 1.0) : 1.0 + 0.25 * (double)terms[g].size();
+  };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+  std::vector<double> load(world, 0.0);
+  std::vector<int> owner(gx.size(), 0);
+  for (int g : order) {
+    int best = 0;
+    for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
+    load[best] += cost(g);
+    owner[g] = best;
+  }
+  return owner;
+}
+
 // Build (or rebuild after re-sharding) the device Hamiltonian.
 int build_hamiltonian(vqe_t* h) {
   const int n = h->n;
   const size_t dim = (size_t)1 << n;
-  // greedy bin packing of X-mask groups over ranks by cost (terms for the streaming path,
-  // table length for the LDS path); deterministic.
-  std::vector<int> order(h->gx_all.size());
-  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-  auto cost = [&](int g) -> double {
-    return h->lds_path ? (h->gx_all[g] == 0 ? 2.0 : 1.0) : 1.0 + 0.25 * h->group_terms[g].size();
-  };
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
-  std::vector<double> load(h->shard_world, 0.0);
+  const std::vector<int> owner = assign_groups(h->gx_all, h->group_terms, h->lds_path, h->shard_world);
   std::vector<int> mine;
-  for (int g : order) {
-    int best = 0;
-    for (int r = 1; r < h->shard_world; ++r) if (load[r] < load[best]) best = r;
-    load[best] += cost(g);
-    if (best == h->shard_rank) mine.push_back(g);
-  }
+  for (size_t g = 0; g < owner.size(); ++g) if (owner[g] == h->shard_rank) mine.push_back((int)g);
   std::sort(mine.begin(), mine.end());
 
   std::vector<uint32_t> gx;
@@ -250,6 +259,7 @@ BatchArgs make_args(vqe_t* h) {
   A.par_count = h->d_par_count.p;
   A.theta = h->d_theta.p;
   A.xout = h->d_x.p;
+  A.xraw = h->d_xraw.p;
   A.new_gate = nullptr;
   A.env_step = 0;
   A.fout = h->d_f.p;
@@ -295,6 +305,7 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   if ((rc = upload(h, h->d_theta, theta0, (size_t)total_params))) return rc;
   HIP_TRY(h, h->d_scratch.reserve((size_t)stot + 2));
   HIP_TRY(h, h->d_x.reserve((size_t)total_params + 1));
+  HIP_TRY(h, h->d_xraw.reserve((size_t)total_params + 1));
   HIP_TRY(h, h->d_f.reserve(batch));
   HIP_TRY(h, h->d_nfev.reserve(batch));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -655,6 +666,18 @@ int vqe_batch_fetch(vqe_t* h, double* x, double* f, int32_t* nfev) {
   return VQE_OK;
 }
 
+int vqe_batch_fetch_xopt(vqe_t* h, double* x) {
+  if (!h) return VQE_EINVAL;
+  if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
+  if (!x && h->total_params) return fail(h, VQE_EINVAL, "x is NULL");
+  if (!h->lds_path) return fail(h, VQE_ESTATE, "unrounded optimum is kept by the LDS-resident path only");
+  HIP_TRY(h, hipSetDevice(h->dev));
+  if (h->total_params)
+    HIP_TRY(h, hipMemcpyAsync(x, h->d_xraw.p, (size_t)h->total_params * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VQE_OK;
+}
+
 int vqe_batch_energy_devptr(vqe_t* h, void** p) {
   if (!h || !p) return VQE_EINVAL;
   if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
@@ -674,6 +697,22 @@ int vqe_last_kernel_ms(vqe_t* h, float* ms) {
   if (!h || !ms) return VQE_EINVAL;
   HIP_TRY(h, hipEventSynchronize(h->ev1));
   HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return VQE_OK;
+}
+
+int vqe_term_owner(int n_qubits, int n_terms, const uint64_t* xmask, int world, int32_t* owner) {
+  if (n_qubits < 1 || n_qubits > 30 || n_terms < 0 || world < 1 || (n_terms > 0 && (!xmask || !owner))) return VQE_EINVAL;
+  std::map<uint32_t, int> index;
+  std::vector<uint32_t> gx;
+  std::vector<std::vector<int>> terms;
+  for (int k = 0; k < n_terms; ++k) {
+    const uint32_t x = (uint32_t)xmask[k];
+    auto it = index.find(x);
+    if (it == index.end()) { it = index.emplace(x, (int)gx.size()).first; gx.push_back(x); terms.emplace_back(); }
+    terms[it->second].push_back(k);
+  }
+  const std::vector<int> go = assign_groups(gx, terms, n_qubits <= 13, world);
+  for (size_t g = 0; g < gx.size(); ++g) for (int k : terms[g]) owner[k] = go[g];
   return VQE_OK;
 }
 

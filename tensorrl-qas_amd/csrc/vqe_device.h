@@ -58,6 +58,7 @@ struct BatchArgs {
   const int32_t* par_count;    // [batch]
   const double* theta;         // [sum P] in: theta / x0 (never written: runs are repeatable)
   double* xout;                // [sum P] out: optimised parameters (minimize / env_step)
+  double* xraw;                // [sum P] out: the same before the float32 rounding of env_step
   const int32_t* new_gate;     // [batch] or NULL: index of the gate the RL action just added
   int env_step;                // 1: after COBYLA round x to float32 and evaluate the full circuit
   double* fout;                // [batch]
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(kThreads) k_lds_minimize(BatchArgs A) {
   double fret;
   if (Popt == 0) {  // scipy returns after a single evaluation for an empty x0
     fret = lds_evaluate<N>(A, b, L, theta, P, noisy, A.noise.eval_base, skip, p_hole);
-    for (int j = threadIdx.x; j < P; j += kThreads) xout[j] = theta[j];
+    for (int j = threadIdx.x; j < P; j += kThreads) { xout[j] = theta[j]; A.xraw[A.par_begin[b] + j] = theta[j]; }
   } else {
     StagedCobyla<N> sc;
     sc.init(A.scratch + A.scratch_begin[b], L, Popt);
@@ -542,6 +543,7 @@ __global__ void __launch_bounds__(kThreads) k_lds_minimize(BatchArgs A) {
     for (int j = threadIdx.x; j < P; j += kThreads) {
       const double v = (j == p_hole) ? theta[j] : cob.x[j - (p_hole >= 0 && j > p_hole)];
       xout[j] = A.env_step ? (double)(float)v : v;
+      A.xraw[A.par_begin[b] + j] = v;
     }
     fret = (cob.status == cby::DONE_RHOEND && cob.ifull == 1) ? flast : cob.fbest_ret;
     nfev = cob.nfvals;

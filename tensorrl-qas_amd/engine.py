@@ -200,6 +200,11 @@ class VQEEngine:
                                             _p(f, c_f64p), _p(nfev, c_i32p)))
         return x, f, nfev
 
+    def batch_fetch_xopt(self):
+        x = np.empty(self._total_params, np.float64)
+        self._chk(self._lib.vqe_batch_fetch_xopt(self._h, _p(x, c_f64p)))
+        return x
+
     def batch_energy_devptr(self) -> int:
         p = C.c_void_p()
         self._chk(self._lib.vqe_batch_energy_devptr(self._h, C.byref(p)))

@@ -1,0 +1,92 @@
+"""Multi-GPU use of the engine: one process per GPU (torch.distributed, backend "nccl" =
+RCCL over xGMI on ROCm; "gloo" in CPU tests).
+
+Two ways the path shards:
+* parallel environments / RL seeds - replicas, no data-path collective (``env_shard``);
+* Pauli-term sharding of <psi|H|psi> - every rank applies the same circuit to its own copy
+  of the state and evaluates a disjoint set of X-mask groups; ONE all-reduce of the partial
+  energies (8 bytes per evaluation) completes each batch of evaluations.
+The reference has no counterpart (single process)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from .engine import HostCobyla
+
+
+def dist_env():
+    """(rank, world_size, local_rank) from the launcher's environment (torchrun)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def env_shard(num_envs_total: int, rank: int, world: int) -> range:
+    """Contiguous block of environment ids owned by ``rank`` (sizes differ by at most 1)."""
+    base, rem = divmod(num_envs_total, world)
+    lo = rank * base + min(rank, rem)
+    return range(lo, lo + base + (1 if rank < rem else 0))
+
+
+def term_owner(n_qubits: int, xmask, world: int) -> np.ndarray:
+    """Rank owning each Pauli term under vqe_set_term_shard(rank, world) (host only)."""
+    x = np.ascontiguousarray(xmask, np.uint64)
+    out = np.zeros(x.size, np.int32)
+    rc = _lib.load().vqe_term_owner(int(n_qubits), int(x.size), x.ctypes.data_as(_lib.c_u64p), int(world),
+                                    out.ctypes.data_as(_lib.c_i32p))
+    if rc:
+        raise _lib.VQEError(f"vqe_term_owner failed ({rc})")
+    return out
+
+
+def allreduce_sum(values, group=None):
+    """Sum a float64 tensor (or array) of partial energies over all ranks, in place."""
+    import torch
+    import torch.distributed as dist
+    t = values if isinstance(values, torch.Tensor) else torch.as_tensor(np.asarray(values, np.float64))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def sharded_minimize(partial_energy, x0, rhobeg=1.0, rhoend=1e-4, maxfun=1000, group=None):
+    """COBYLA where every evaluation is ``allreduce_sum(partial_energy(x))``.  All ranks run
+    the same ask/tell sequence on bit-identical reduced energies, so they stay in lock-step
+    without broadcasting x.  ``partial_energy(x) -> float`` (this rank's share)."""
+    opt = HostCobyla(x0, rhobeg, rhoend, maxfun)
+    while True:
+        x = opt.ask()
+        if x is None:
+            break
+        e = allreduce_sum(np.array([partial_energy(x)], np.float64), group)
+        opt.tell(float(e[0]))
+    return opt.result()
+
+
+class TermShardedEngine:
+    """An engine that owns ``rank``'s share of the Pauli terms; ``energies()`` returns the
+    all-reduced energies of the resident batch as a device tensor."""
+
+    def __init__(self, engine, rank: int, world: int, device):
+        import torch
+        self.engine, self.rank, self.world = engine, rank, world
+        self.device = torch.device(device)
+        engine.set_term_shard(rank, world)
+        self._buf = None
+
+    def energies(self, batch: int):
+        import torch
+        if self._buf is None or self._buf.numel() != batch:
+            self._buf = torch.zeros(batch, dtype=torch.float64, device=self.device)
+        self.engine.batch_run_energy()
+        self.engine.batch_copy_energy(self._buf.data_ptr())
+        return allreduce_sum(self._buf)
+
+    def minimize(self, circuit, x0, rhobeg=1.0, rhoend=1e-4, maxfun=1000):
+        def partial(x):
+            self.engine.batch_load([circuit], [x])
+            return float(self.energies(1)[0].item())
+        return sharded_minimize(partial, x0, rhobeg, rhoend, maxfun)

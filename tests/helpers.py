@@ -62,3 +62,38 @@ def random_hamiltonian(n, T, rng, real=True):
             continue
         xs.append(x), zs.append(z), cs.append(float(rng.normal()))
     return np.array(xs, np.uint64), np.array(zs, np.uint64), np.array(cs)
+
+
+STEMS = {
+    "H2O_8q": "H2O_8q_geom_H_-0.021_-0.002_0.000;_O_0.835_0.452_0.000;_H_1.477_-0.273_0.000_jordan_wigner",
+    "CH2_8q": "CH2_8q_geom_C_0.000_0.000_0.000;_H_1.080_0.000_0.000;_H_-0.225_1.056_0.000_jordan_wigner",
+    "BEH2_6q": "BEH2_6q_geom_H_0.000_0.000_-1.330;_Be_0.000_0.000_0.000;_H_0.000_0.000_1.330_jordan_wigner",
+    "heisenberg_5q": "heisenberg_5q",
+}
+
+
+def make_data_root(root):
+    """Lay the golden fixtures out like the reference's dmrg-to-qc/ directory (mol_data/*.npz,
+    init_state_circ/*.qasm) so CircuitEnv can be built from an unmodified config."""
+    os.makedirs(os.path.join(root, "mol_data"), exist_ok=True)
+    os.makedirs(os.path.join(root, "init_state_circ"), exist_ok=True)
+    for case, stem in STEMS.items():
+        d = load_case(case)
+        np.savez(os.path.join(root, "mol_data", stem + ".npz"), paulis=np.array(d["paulis"]),
+                 weights=d["weights"], eigvals=d["eigvals"], energy_shift=0)
+        lines = ["OPENQASM 2.0;", 'include "qelib1.inc";', f"qreg q[{d['n']}];"]
+        for name, qs, ang in d["gates"]:
+            if name == "cx":
+                lines.append(f"cx q[{qs[0]}],q[{qs[1]}];")
+            else:
+                lines.append(f"{name}({ang!r}) q[{qs[0]}];")
+        with open(os.path.join(root, "init_state_circ", f"init_{stem}_TNbond2.qasm"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    return root
+
+
+def reference_config(name, data_root):
+    conf = json.load(open(os.path.join(GOLDEN, "host_logic.json")))["configs"][name]
+    conf = json.loads(json.dumps(conf))
+    conf["env"]["data_root"] = data_root
+    return conf

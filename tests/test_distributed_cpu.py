@@ -1,0 +1,76 @@
+"""CPU, world_size 2, gloo: the N > 1 paths - Pauli-term sharding (disjoint cover, partial
+energies all-reduce to the full energy, lock-step sharded COBYLA) and environment sharding."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import vqe_oracle as vo
+from helpers import load_case, oracle_init_state, random_gates
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import tensorrl_qas_amd as tq
+    from tensorrl_qas_amd import parallel
+    d = load_case("H2O_8q")
+    n = d["n"]
+    xs, zs = tq.hamiltonian.masks_from_strings(d["paulis"], n)
+    owner = parallel.term_owner(n, xs, world)
+    mine = owner == rank
+    psi0 = oracle_init_state(d)
+    rng = np.random.default_rng(0)
+    kind, q0, q1, pidx, th = random_gates(n, 10, rng)
+
+    def partial(x):      # the ORACLE stands in for the GPU here: only the sharding logic is under test
+        psi = vo.run_circuit(psi0, kind, q0, q1, pidx, x)
+        return vo.energy_pauli(psi, xs[mine], zs[mine], d["weights"][mine])
+
+    full = vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th), xs, zs, d["weights"])
+    tot = parallel.allreduce_sum(np.array([partial(th)]))
+    x, f, nfev, status = parallel.sharded_minimize(partial, th, 1.0, 1e-4, 120)
+    envs = list(parallel.env_shard(11, rank, world))
+    counts = torch.tensor([int(mine.sum())])
+    dist.all_reduce(counts)
+    out[rank] = dict(total=float(tot[0]), full=full, x=x.tolist(), f=f, nfev=nfev, envs=envs,
+                     covered=int(counts[0]), n_terms=len(xs), groups_split=bool(
+                         len(set(xs[mine].tolist()) & set(xs[~mine].tolist()))))
+    dist.destroy_process_group()
+
+
+def test_term_and_env_sharding_two_ranks():
+    world = 2
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        r0, r1 = out[0], out[1]
+    assert abs(r0["total"] - r0["full"]) < 1e-10 and r0["total"] == r1["total"]
+    assert r0["covered"] == r0["n_terms"] and not r0["groups_split"] and not r1["groups_split"]
+    assert r0["x"] == r1["x"] and r0["nfev"] == r1["nfev"] and r0["f"] == r1["f"]      # lock-step
+    assert r0["f"] <= r0["full"] + 1e-12
+    assert sorted(r0["envs"] + r1["envs"]) == list(range(11)) and abs(len(r0["envs"]) - len(r1["envs"])) <= 1
+
+
+def test_term_owner_partitions():
+    import tensorrl_qas_amd as tq
+    from tensorrl_qas_amd import parallel
+    hh, _ = tq.hamiltonian.heisenberg(20)
+    for world in (1, 2, 4, 8):
+        own = parallel.term_owner(20, hh.xmask, world)
+        assert own.min() == 0 and own.max() == world - 1
+        for x in np.unique(hh.xmask):
+            assert len(set(own[hh.xmask == x].tolist())) == 1          # a group is never split
+        sizes = [int((own == r).sum()) for r in range(world)]
+        assert sum(sizes) == 77

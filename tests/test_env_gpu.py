@@ -1,0 +1,175 @@
+"""GPU: CircuitEnv end to end (reset / step / get_energy / illegal_action_new) through
+unmodified reference configs, checked step by step against the CPU oracle restating
+CircuitEnv.step (environments/environment_qulacs_TN_notin_agent.py:230-333)."""
+import numpy as np
+import pytest
+import torch
+
+import vqe_oracle as vo
+from helpers import known_answers, load_case, make_data_root, oracle_init_state, reference_config
+
+pytestmark = pytest.mark.gpu
+E_TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def data_root(tmp_path_factory):
+    return make_data_root(str(tmp_path_factory.mktemp("dmrg-to-qc")))
+
+
+def _oracle_energy(env, state, psi0, case, reverse):
+    n = env.num_qubits
+    k, a, b, p, th = vo.ansatz_from_state(state.numpy(), n)
+    xs, zs = vo.pauli_masks(case["paulis"], n, reverse=reverse)
+    return vo.energy_pauli(vo.run_circuit(psi0, k, a, b, p, th), xs, zs, case["weights"])
+
+
+def test_fixed_env_episode(data_root):
+    from tensorrl_qas_amd.environments.environment_qulacs_TN_notin_agent import CircuitEnv
+    from tensorrl_qas_amd.environments.utils.utils import dictionary_of_actions
+    conf = reference_config("TensorRL_fixed/H2O8q_TNbond2", data_root)
+    conf["non_local_opt"]["global_iters"] = 300
+    case = load_case("H2O_8q")
+    psi0 = oracle_init_state(case)
+    dev = torch.device("cuda:0")
+    env = CircuitEnv(conf, dev)
+    n, L = env.num_qubits, env.num_layers
+    assert (n, env.state_size, env.action_size) == (8, L * 8 * 14, 80)
+    assert env.num_layers_termination == L - 27
+    assert np.abs(env.TN_state - psi0).max() < 1e-12
+    obs = env.reset()
+    gold = known_answers()["H2O_8q"]
+    assert obs.shape == (L * (n + 3) * n,) and obs.device.type == "cuda" and float(obs.abs().sum()) == 0
+    assert abs(env.prev_energy - gold["e_init_fixed"]) < E_TOL
+    assert abs(env.min_eig - gold["min_eig"]) < 1e-12 and env.done_threshold == conf["env"]["accept_err"]
+    table = dictionary_of_actions(n)
+    # CNOT(0->1), RY(q1), RX(q1), CNOT(1->3), RZ(q3), RY(q0)
+    script = [0, 56 + 1 * 3 + 1, 56 + 1 * 3 + 0, 7 + 1, 56 + 3 * 3 + 2, 56 + 0 * 3 + 1]
+    expect_layer = [0, 1, 2, 3, 4, 1]
+    moments = [0] * n
+    prev_state, prev_e = env.state.clone(), env.prev_energy
+    for step, (ai, lay) in enumerate(zip(script, expect_layer)):
+        act = table[ai]
+        ill = env.illegal_action_new()
+        assert ai not in ill or step == 0
+        obs, rwd, done = env.step(act)
+        s = env.state
+        # placement
+        if act[0] < n:
+            c, t = act[0], (act[0] + act[1]) % n
+            assert s[lay][t][c] == 1
+        else:
+            assert s[lay][n + act[3] - 1][act[2]] == 1
+        assert int((s[:, :n + 3] == 1).sum()) == step + 1
+        # angles are float32 and the new rotation entered with 0
+        if act[2] < n:
+            assert float(s[lay][n + 3 + act[3] - 1][act[2]]) == 0.0
+        # energy of the committed state, against the oracle
+        e_ref = _oracle_energy(env, s, psi0, case, reverse=False)
+        assert abs(env.energy - e_ref) < E_TOL
+        assert abs(env.error - abs(env.min_eig - e_ref)) < E_TOL
+        # optimiser lag: the pre-action circuit with the committed angles is no worse than before
+        pre = prev_state.clone()
+        pre[:, n + 3:] = s[:, n + 3:] * (prev_state[:, n:n + 3] == 1)
+        e_pre = _oracle_energy(env, pre, psi0, case, reverse=False)
+        assert e_pre <= prev_e + 1e-6 or step == 0
+        # reward
+        if env.error < conf["env"]["accept_err"]:
+            assert float(rwd) == 5.0
+        else:
+            want = np.clip((prev_e - env.energy) / abs(prev_e - env.min_eig), -1, 1)
+            assert abs(float(rwd) - np.float32(want)) < 1e-6
+        assert rwd.dtype == torch.float32 and rwd.device.type == "cuda" and obs.shape == (L * (n + 3) * n,)
+        assert env.nfev >= 1 and done in (0, 1)
+        n_rot = int((prev_state[:, n:n + 3] == 1).sum())
+        assert np.asarray(env.opt_ang_save).size == n_rot
+        if n_rot == 0:
+            assert env.nfev == 1
+        prev_state, prev_e = s.clone(), float(env.prev_energy)
+        if done:
+            break
+    e1, e2 = env.get_energy()
+    assert e1 == e2 and abs(e1 - env.energy) < 1e-12
+    # a fresh episode starts from the TN state again
+    env.reset()
+    assert abs(env.prev_energy - gold["e_init_fixed"]) < E_TOL and env.step_counter == -1
+
+
+def test_episode_terminates_at_depth_budget(data_root):
+    from tensorrl_qas_amd.environments.environment_qulacs_TN_notin_agent import CircuitEnv
+    from tensorrl_qas_amd.environments.utils.utils import dictionary_of_actions
+    conf = reference_config("TensorRL_fixed/heisenberg_5q_TNbond2", data_root)
+    conf["non_local_opt"]["global_iters"] = 60
+    conf["env"]["num_layers"] = 27 + 4
+    env = CircuitEnv(conf, torch.device("cuda:0"))
+    env.reset()
+    table = dictionary_of_actions(5)
+    dones = []
+    for ai in (0, 21, 9, 24):
+        _, rwd, done = env.step(table[ai])
+        dones.append(done)
+    assert dones[:3] == [0, 0, 0] or 1 in dones[:3]
+    assert dones[-1] == 1
+    if env.error >= env.done_threshold:
+        assert float(rwd) == -5.0
+
+
+def test_trainable_env_reset_and_step(data_root):
+    from tensorrl_qas_amd.environments.environment_qulacs import CircuitEnv
+    from tensorrl_qas_amd.environments.utils.utils import dictionary_of_actions
+    conf = reference_config("TensorRL_trainable/H2O8q_TNbond2", data_root)
+    conf["non_local_opt"]["global_iters"] = 150
+    case = load_case("H2O_8q")
+    env = CircuitEnv(conf, torch.device("cuda:0"))
+    n = env.num_qubits
+    env.reset()
+    assert int((env.state[:, :n + 3] == 1).sum()) == 150
+    assert abs(env.prev_energy - (-73.29140413242818)) < 1e-9        # SURVEY 8c, trainable encoding
+    zero = np.eye(1, 2 ** n)[0].astype(complex)
+    assert abs(env.prev_energy - _oracle_energy(env, env.state, zero, case, reverse=True)) < E_TOL
+    act = dictionary_of_actions(n)[56 + 2 * 3 + 1]
+    obs, rwd, done = env.step(act)
+    assert env.state[27][n + 1][2] == 1                              # first free layer after the TN circuit
+    assert env.nfev == 150                                            # 129 parameters: maxfun reached
+    assert abs(env.energy - _oracle_energy(env, env.state, zero, case, reverse=True)) < E_TOL
+    assert env.energy <= -73.29140413242818 + 1e-6
+
+
+def test_noisy_env_smoke(data_root):
+    from tensorrl_qas_amd.environments.environment_qulacs_TN_notin_agent_noise import CircuitEnv
+    from tensorrl_qas_amd.environments.utils.utils import dictionary_of_actions
+    conf = reference_config("TensorRL_fixed/H2O8q_TNbond2_noise", data_root)
+    conf["non_local_opt"]["global_iters"] = 80
+    env = CircuitEnv(conf, torch.device("cuda:0"), seed=5)
+    env.reset()
+    table = dictionary_of_actions(env.num_qubits)
+    for ai in (3, 60, 20, 70):
+        obs, rwd, done = env.step(table[ai])
+        assert env.min_eig - 1e-9 <= env.energy <= env.max_eig + 1e-9
+        assert torch.isfinite(rwd)
+
+
+def test_vec_env_equals_single_envs(data_root):
+    from tensorrl_qas_amd.environments.environment_qulacs_TN_notin_agent import CircuitEnv
+    from tensorrl_qas_amd.environments.vec_env import VecCircuitEnv
+    from tensorrl_qas_amd.environments.utils.utils import dictionary_of_actions
+    conf = reference_config("TensorRL_fixed/BEH26q_TNbond2", data_root)
+    conf["non_local_opt"]["global_iters"] = 120
+    dev = torch.device("cuda:0")
+    B = 5
+    vec = VecCircuitEnv(CircuitEnv, conf, dev, B)
+    obs = vec.reset()
+    assert obs.shape[0] == B
+    table = dictionary_of_actions(6)
+    rng = np.random.default_rng(1)
+    scripts = [[int(a) for a in rng.integers(0, len(table), 4)] for _ in range(B)]
+    singles = [CircuitEnv(conf, dev) for _ in range(B)]
+    for e in singles:
+        e.reset()
+    for t in range(4):
+        o, r, d = vec.step([table[s[t]] for s in scripts])
+        for b, e in enumerate(singles):
+            o1, r1, d1 = e.step(table[scripts[b][t]])
+            assert torch.equal(o[b], o1) and float(r[b]) == float(r1) and d[b] == d1
+            assert vec.envs[b].energy == e.energy and vec.envs[b].nfev == e.nfev
+            assert torch.equal(vec.envs[b].state, e.state)

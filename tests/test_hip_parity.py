@@ -288,3 +288,42 @@ def test_env_step_semantics(tq):
             full[sel] = r.x.astype(np.float32)
             e_ref = vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, full), *ham)
             assert abs(f[b] - e_ref) < 1e-3, (b, f[b], e_ref, nfev[b], r.nfev)  # optimiser tolerance (rhoend is a step size)
+
+
+def test_noise_trajectories_match_oracle(tq):
+    """Stochastic Pauli noise: the engine's draw for (stream, evaluation, gate) is a pure
+    function of the seed, restated in the C oracle; with the same draws the noisy energies
+    agree to 1e-10 (X, Y and Z errors on both qubits of a CNOT included)."""
+    import c_oracle as co
+    n = 6
+    rng = np.random.default_rng(21)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 50, rng, real=False)
+    base = random_gates(n, 30, rng)
+    kind, q0, q1, pidx = [], [], [], []
+    for k, a, b, p in zip(*base[:4]):
+        kind.append(k), q0.append(a), q1.append(b), pidx.append(p)
+        kind.append(5 if k == 0 else 4), q0.append(a), q1.append(b if k == 0 else -1), pidx.append(-1)
+    kind, q0, q1, pidx = (np.array(v, np.int32) for v in (kind, q0, q1, pidx))
+    th = base[4]
+    p1, p2, seed = 0.3, 0.6, 987654321
+    eng = _engine(tq, n, psi0, ham)
+    eng.set_noise(p1, p2, seed)
+    eng.set_circuit(tq.Circuit(kind, q0, q1, pidx, th.size))
+    kinds_seen = set()
+    for e in range(12):                       # evaluation counter starts at 0, +1 per energy run
+        got = eng.energy(th)
+        dr = co.noise_draws(seed, 0, e, kind, p1, p2)
+        kinds_seen.update(dr.tolist())
+        ref = vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th, dr), *ham)
+        assert abs(got - ref) < E_TOL, (e, got, ref)
+    assert len(kinds_seen) > 6
+    # batch: stream index enters the draw
+    got = eng.energy_batch(np.tile(th, (5, 1)))
+    for b in range(5):
+        dr = co.noise_draws(seed, b, 12, kind, p1, p2)
+        ref = vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th, dr), *ham)
+        assert abs(got[b] - ref) < E_TOL
+    # state incl. the global phase of Y errors
+    dr = co.noise_draws(seed, 0, 13, kind, p1, p2)
+    assert np.abs(eng.get_state(th) - vo.run_circuit(psi0, kind, q0, q1, pidx, th, dr)).max() < A_TOL

@@ -1,0 +1,180 @@
+"""CPU: the Python host (config, action tables, curricula, illegal actions, reward, QASM,
+Hamiltonian helpers, state-tensor -> circuit) against fixtures recorded from the
+reference's importable modules (tests/golden/host_logic.json) and against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vqe_oracle as vo
+from helpers import CASES, GOLDEN, load_case
+
+import tensorrl_qas_amd as tq
+from tensorrl_qas_amd.environments._core import CircuitEnvBase
+from tensorrl_qas_amd.environments.utils import curricula, utils
+
+HL = json.load(open(os.path.join(GOLDEN, "host_logic.json")))
+
+
+def test_action_tables():
+    for n, table in HL["actions"].items():
+        got = utils.dictionary_of_actions(int(n))
+        assert [got[i] for i in range(len(got))] == table
+    for n, table in HL["actions_revert"].items():
+        got = utils.dict_of_actions_revert_q(int(n))
+        assert [got[i] for i in range(len(got))] == table
+    d = utils.dictionary_of_actions(4)
+    assert d[0] == [0, 1, 4, 0] and d[11] == [3, 3, 4, 0] and d[12] == [4, 0, 0, 1] and d[23] == [4, 0, 3, 3]
+
+
+def test_get_config_matches_reference(tmp_path):
+    """Re-serialise each recorded config as an INI file and parse it with our get_config."""
+    import configparser
+    assert len(HL["configs"]) == 37
+    for name, conf in HL["configs"].items():
+        cp = configparser.ConfigParser()
+        for sec, kv in conf.items():
+            cp[sec] = {k: (json.dumps(v) if isinstance(v, list) else str(v)) for k, v in kv.items()}
+        f = tmp_path / "c.cfg"
+        with open(f, "w") as fh:
+            cp.write(fh)
+        got = utils.get_config("c", ".cfg", path=str(tmp_path))
+        assert got == conf, name
+    lih = HL["configs"]["TensorRL_fixed/LIH12q_TNbond2"]
+    assert lih["env"]["num_qubits"] == 12 and lih["non_local_opt"]["a"] == "0." and lih["agent"]["init_epsilon"] == "1.0"
+
+
+def _bare_env(n):
+    e = object.__new__(CircuitEnvBase)
+    e.num_qubits = n
+    e.illegal_actions = [[]] * n
+    e._actions_table = utils.dictionary_of_actions(n)
+    return e
+
+
+def test_illegal_actions_match_reference_traces():
+    for tr in HL["illegal_traces"]:
+        n = tr["n"]
+        e = _bare_env(n)
+        table = utils.dictionary_of_actions(n)
+        for a, (first, second) in zip(tr["actions"], tr["illegal"]):
+            e.current_action = table[a]
+            assert e.illegal_action_new() == first
+            assert e.illegal_action_new() == second
+
+
+def test_reward_matches_reference():
+    for r in HL["reward"]:
+        e = object.__new__(CircuitEnvBase)
+        e.fn_type = "incremental_with_fixed_ends"
+        e.num_layers_termination = 20
+        e.step_counter = r["step_counter"]
+        e.done_threshold = 1.6e-3
+        e.min_eig = -5.0
+        e.prev_energy = r["prev_energy"]
+        e.error = abs(e.min_eig - r["energy"])
+        assert float(e.reward_fn(r["energy"])) == r["reward"]
+
+
+def test_curricula_match_reference():
+    c = HL["curricula"]["vanilla"]
+    cur = curricula.VanillaCurriculum(c["conf"], target_energy=-1.0)
+    got = []
+    for _ in c["trace"]:
+        got.append(cur.get_current_threshold())
+        cur.update_threshold(energy_done=1)
+    assert got == c["trace"]
+    m = HL["curricula"]["moving"]
+    cur = curricula.MovingThreshold(m["conf"], target_energy=-1.0)
+    rng = np.random.default_rng(m["rng_seed"])
+    dones = [int(v) for v in rng.integers(0, 2, 40)]
+    assert dones == m["dones"]
+    got = []
+    for d in dones:
+        cur.lowest_energy = min(cur.lowest_energy, -1.0 + 5e-3 * float(rng.random()))
+        cur.update_threshold(energy_done=d)
+        got.append(cur.get_current_threshold())
+    assert got == m["trace"]
+
+
+def test_qasm_parser_matches_oracle_and_fixture():
+    text = open(os.path.join(GOLDEN, "init_heisenberg_5q_TNbond2.qasm")).read()
+    n, gates = tq.qasm.parse(text)
+    n2, ref = vo.parse_qasm(text)
+    assert n == n2 == 5 and len(gates) == len(ref) == 87
+    for g, (name, qs, ang) in zip(gates, ref):
+        assert g.name == name and list(g.qubits) == qs and (g.angle is None) == (ang is None)
+        assert ang is None or g.angle == ang
+    assert len(tq.qasm.layers(n, gates)) == 27
+    with pytest.raises(ValueError):
+        tq.qasm.parse("OPENQASM 2.0; qreg q[2]; h q[0];")
+    with pytest.raises(ValueError):
+        tq.qasm.parse("OPENQASM 2.0; qreg q[2]; rx(__import__('os')) q[0];")
+    assert tq.qasm.parse_angle("-3*pi/2") == -1.5 * np.pi
+    for case in CASES:
+        d = load_case(case)
+        assert len(tq.qasm.layers(d["n"], [tq.qasm.QasmGate(*g) for g in d["gates"]])) == 27
+
+
+def test_masks_and_dense_decomposition():
+    for case, rev in (("H2O_8q", False), ("BEH2_6q", True)):
+        d = load_case(case)
+        xs, zs = tq.hamiltonian.masks_from_strings(d["paulis"], d["n"], reverse=rev)
+        rx, rz = vo.pauli_masks(d["paulis"], d["n"], reverse=rev)
+        assert np.array_equal(xs, rx) and np.array_equal(zs, rz)
+    d4 = np.load(os.path.join(GOLDEN, "ham_LIH_4q.npz"))
+    h = d4["hamiltonian"].astype(np.complex128)
+    for rev in (False, True):
+        xs, zs, cs = tq.hamiltonian.pauli_from_dense(h, reverse_qargs=rev)
+        idx = np.arange(16)
+        m = np.zeros((16, 16), complex)
+        for x, z, c in zip(xs, zs, cs):
+            x, z = int(x), int(z)
+            m[idx ^ x, idx] += c * (1 - 2 * vo._parity(idx & z)) * (1j ** bin(x & z).count("1"))
+        want = vo.reverse_qargs(h) if rev else h
+        assert np.abs(m - want).max() < 1e-12
+        assert abs(np.linalg.eigvalsh(m).min() - d4["eigvals"].min()) < 1e-6     # complex64 source
+    hh, strings = tq.hamiltonian.heisenberg(20)
+    assert hh.n_terms == 77 and hh.n_xgroups == 20 and strings == vo.heisenberg_paulis(20)[0]
+    lih = tq.hamiltonian.synthetic_lih12()
+    assert lih.n_terms == 631 and lih.n_xgroups == 91
+    assert np.all(np.array([bin(int(x) & int(z)).count("1") for x, z in zip(lih.xmask, lih.zmask)]) % 2 == 0)
+    psi = tq.hamiltonian.brickwork_state(6, 3)
+    assert abs(np.vdot(psi, psi).real - 1) < 1e-12
+
+
+def test_circuit_from_state_matches_oracle_ordering():
+    rng = np.random.default_rng(0)
+    n, L = 5, 7
+    s = torch.zeros((L, n + 6, n))
+    for _ in range(25):
+        l = int(rng.integers(L))
+        if rng.random() < 0.5:
+            c, t = rng.choice(n, 2, replace=False)
+            s[l][t][c] = 1
+        else:
+            a, q = int(rng.integers(3)), int(rng.integers(n))
+            s[l][n + a][q] = 1
+            s[l][n + 3 + a][q] = float(rng.normal())
+    for noise in (False, True):
+        circ, ang, lay = tq.circuits.circuit_from_state(s, n, noise=noise, with_layers=True)
+        k, a, b, p, th = vo.ansatz_from_state(s.numpy(), n, noise=noise)
+        assert np.array_equal(circ.kind, k) and np.array_equal(circ.q0, a) and np.array_equal(circ.q1, b)
+        assert np.array_equal(circ.pidx, p) and np.array_equal(ang, th) and circ.n_params == th.size
+        assert np.all(np.diff(lay) >= 0) and lay.size == k.size
+
+
+def test_batch_generator_shapes():
+    import bench
+    b = bench.make_batch(tq, 12, 16, 64, 1000)
+    assert b["kind"].size == 16 * 64 and b["par_off"][-1] == b["theta"].size
+    for i in range(16):
+        g = slice(b["gate_off"][i], b["gate_off"][i + 1])
+        rot = b["kind"][g] > 0
+        assert np.array_equal(b["pidx"][g][rot], np.arange(rot.sum())) and np.all(b["pidx"][g][~rot] == -1)
+        assert np.all(b["q0"][g][~rot] != b["q1"][g][~rot])
+        if rot[-1]:
+            assert b["theta"][b["par_off"][i + 1] - 1] == 0.0
+    assert np.array_equal(b["theta"], b["theta"].astype(np.float32).astype(np.float64))
