@@ -33,12 +33,40 @@
 
 namespace cby {
 
-// Execution context for the host: one thread, no synchronisation.
+#if defined(__HIPCC__)
+#define CBY_UNROLL _Pragma("unroll 4")
+#else
+#define CBY_UNROLL
+#endif
+
+// Execution context for the host: one thread, no synchronisation, sums in index order (the
+// order of the published algorithm, so iterates match scipy's Fortran build bit for bit).
+// A device context provides the same members with block-wide reductions (vqe_device.h).
 struct HostCtx {
   static constexpr int tid = 0;
   static constexpr int nth = 1;
   CBY_HD void sync() const {}
   CBY_HD int all_or(int v) const { return v; }
+  // sum_{i<n} f(i), identical in every thread
+  template <class F>
+  CBY_HD double sum(int n, F f) const {
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) a += f(i);
+    return a;
+  }
+  // first index whose f(i) is the strict extreme beyond `thresh` (max if want_max else min);
+  // -1 when no f(i) beats thresh.  *val receives the extreme (or thresh).
+  template <class F>
+  CBY_HD int arg_first(int n, F f, double thresh, bool want_max, double* val) const {
+    int idx = -1;
+    double best = thresh;
+    for (int i = 0; i < n; ++i) {
+      const double v = f(i);
+      if (want_max ? (v > best) : (v < best)) { best = v; idx = i; }
+    }
+    *val = best;
+    return idx;
+  }
 };
 
 enum Status { RUNNING = 0, DONE_RHOEND = 1, DONE_MAXFUN = 2, DONE_ROUNDING = 3 };
@@ -143,12 +171,12 @@ struct CobylaM0 {
     const double tinv = 1.0 / zdota;
     for (int i = ctx.tid; i < n; i += ctx.nth) {
       double z = sigbar[i];
+      CBY_UNROLL
       for (int k = i - 1; k >= 0; --k) z = w[k] * z;
       dx[i] = tinv * z;  // sdirn
     }
     ctx.sync();
-    double ss = 0.0;
-    for (int i = 0; i < n; ++i) ss += dx[i] * dx[i];
+    const double ss = ctx.sum(n, [&](int i) { return dx[i] * dx[i]; });
     const double dd = rho * rho;
     const double temp = sqrt(ss * dd);
     const double step = dd / (temp + 0.0);
@@ -206,13 +234,10 @@ struct CobylaM0 {
     for (;;) {
       if (lbl == 140) {
         // ---- identify the optimal vertex and move it to the pole position
-        double phimin = datmat[n];
-        int nbest = n;
-        for (int j = 0; j < n; ++j) {
-          const double t = datmat[j];
-          if (t < phimin) { nbest = j; phimin = t; }
-          // tie rule compares the (all-zero) constraint violations: never switches
-        }
+        // (the tie rule compares the all-zero constraint violations: never switches)
+        double phimin;
+        int nbest = ctx.arg_first(n, [&](int j) { return datmat[j]; }, datmat[n], false, &phimin);
+        if (nbest < 0) nbest = n;
         ctx.sync();
         if (nbest < n) {
           if (ctx.tid == 0) { const double t = datmat[n]; datmat[n] = datmat[nbest]; datmat[nbest] = t; }
@@ -221,6 +246,7 @@ struct CobylaM0 {
             SIM(i, nbest) = 0.0;
             SIM(i, n) += temp;
             double tempa = 0.0;
+            CBY_UNROLL
             for (int k = 0; k < n; ++k) { SIM(i, k) -= temp; tempa -= SIMI(k, i); }
             w[i] = tempa;  // becomes SIMI(nbest, i); deferred so column sums read old values
           }
@@ -242,6 +268,7 @@ struct CobylaM0 {
         const double fp = datmat[n];
         for (int i = ctx.tid; i < n; i += ctx.nth) {
           double temp = 0.0;
+          CBY_UNROLL
           for (int j = 0; j < n; ++j) temp += (datmat[j] - fp) * SIMI(j, i);
           a[i] = -temp;
         }
@@ -251,6 +278,7 @@ struct CobylaM0 {
         int flag_bad = 0;
         for (int j = ctx.tid; j < n; j += ctx.nth) {
           double wsig = 0.0, weta = 0.0;
+          CBY_UNROLL
           for (int i = 0; i < n; ++i) { wsig += SIMI(j, i) * SIMI(j, i); weta += SIM(i, j) * SIM(i, j); }
           const double vs = 1.0 / sqrt(wsig), ve = sqrt(weta);
           vsig[j] = vs; veta[j] = ve;
@@ -259,14 +287,12 @@ struct CobylaM0 {
         iflag = ctx.all_or(flag_bad) ? 0 : 1;  // all_or synchronises
         if (ibrnch == 1 || iflag == 1) { lbl = 370; continue; }
         // ---- geometry step: replace the worst-placed vertex
-        int jd = -1;
-        double temp = pareta;
-        for (int j = 0; j < n; ++j) if (veta[j] > temp) { jd = j; temp = veta[j]; }
-        if (jd < 0) for (int j = 0; j < n; ++j) if (vsig[j] < temp) { jd = j; temp = vsig[j]; }
+        double temp;
+        int jd = ctx.arg_first(n, [&](int j) { return veta[j]; }, pareta, true, &temp);
+        if (jd < 0) jd = ctx.arg_first(n, [&](int j) { return vsig[j]; }, pareta, false, &temp);
         jdrop = jd;
         temp = 0.5 * rho * vsig[jdrop];
-        double sum = 0.0;
-        for (int i = 0; i < n; ++i) sum += a[i] * (temp * SIMI(jdrop, i));
+        const double sum = ctx.sum(n, [&](int i) { return a[i] * (temp * SIMI(jdrop, i)); });
         // dxsign = -1 iff parmu*(cvmaxp-cvmaxm) > 2*sum with parmu = 0
         const double dxsign = (0.0 > sum + sum) ? -1.0 : 1.0;
         ctx.sync();
@@ -284,13 +310,11 @@ struct CobylaM0 {
       if (lbl == 370) {
         trstlp_m0();
         if (ifull == 0) {
-          double t = 0.0;
-          for (int i = 0; i < n; ++i) t += dx[i] * dx[i];
+          const double t = ctx.sum(n, [&](int i) { return dx[i] * dx[i]; });
           if (t < 0.25 * rho * rho) { ibrnch = 1; lbl = 550; continue; }
         }
-        double sum = 0.0;
-        for (int i = 0; i < n; ++i) sum -= a[i] * dx[i];
-        prerem = 0.0 - sum;  // parmu * prerec - sum with parmu = 0, prerec = 0
+        // sum = 0 - a.dx accumulated term by term; prerem = parmu*prerec - sum with parmu = 0
+        prerem = ctx.sum(n, [&](int i) { return a[i] * dx[i]; });
         ctx.sync();
         for (int i = ctx.tid; i < n; i += ctx.nth) x[i] = SIM(i, n) + dx[i];
         ibrnch = 1;
@@ -305,14 +329,14 @@ struct CobylaM0 {
         double ratio = (trured <= 0.0) ? 1.0 : 0.0;
         for (int j = ctx.tid; j < n; j += ctx.nth) {
           double t = 0.0;
+          CBY_UNROLL
           for (int i = 0; i < n; ++i) t += SIMI(j, i) * dx[i];
           t = fabs(t);
           w[j] = t;
           sigbar[j] = t * vsig[j];
         }
         ctx.sync();
-        int jd = -1;
-        for (int j = 0; j < n; ++j) if (w[j] > ratio) { jd = j; ratio = w[j]; }
+        int jd = ctx.arg_first(n, [&](int j) { return w[j]; }, ratio, true, &ratio);
         ctx.sync();
         for (int j = ctx.tid; j < n; j += ctx.nth) {
           double t = -1.0;
@@ -320,6 +344,7 @@ struct CobylaM0 {
             t = veta[j];
             if (trured > 0.0) {
               t = 0.0;
+              CBY_UNROLL
               for (int i = 0; i < n; ++i) { const double d = dx[i] - SIM(i, j); t += d * d; }
               t = sqrt(t);
             }
@@ -327,9 +352,8 @@ struct CobylaM0 {
           w[j] = t;
         }
         ctx.sync();
-        double edgmax = 1.1 * rho;
-        int l = -1;
-        for (int j = 0; j < n; ++j) if (w[j] > edgmax) { l = j; edgmax = w[j]; }
+        double edgmax;
+        const int l = ctx.arg_first(n, [&](int j) { return w[j]; }, 1.1 * rho, true, &edgmax);
         if (l >= 0) jd = l;
         if (jd < 0) { lbl = 550; continue; }
         jdrop = jd;
@@ -357,15 +381,16 @@ struct CobylaM0 {
 
   // Rank-one update of SIMI after vertex jdrop was replaced by pole + dx.
   CBY_HD void update_simi() {
-    double temp = 0.0;
-    for (int i = 0; i < n; ++i) temp += SIMI(jdrop, i) * dx[i];
+    const double temp = ctx.sum(n, [&](int i) { return SIMI(jdrop, i) * dx[i]; });
     ctx.sync();
     for (int i = ctx.tid; i < n; i += ctx.nth) SIMI(jdrop, i) /= temp;
     ctx.sync();
     for (int j = ctx.tid; j < n; j += ctx.nth) {
       if (j == jdrop) continue;
       double t = 0.0;
+      CBY_UNROLL
       for (int i = 0; i < n; ++i) t += SIMI(j, i) * dx[i];
+      CBY_UNROLL
       for (int i = 0; i < n; ++i) SIMI(j, i) -= t * SIMI(jdrop, i);
     }
     ctx.sync();

@@ -1,4 +1,4 @@
-// vqe_api.hip - host side of libvqe_hip.so: handle management, Hamiltonian tables, batch
+// vqe_api.hip - host side of libvqe_hip.so: handle management, Hamiltonian layout, batch
 // upload and kernel dispatch behind the C ABI of include/vqe_hip.h.
 #include "../../include/vqe_hip.h"
 #include "vqe_device.h"
@@ -53,8 +53,8 @@ struct vqe_handle {
   int shard_rank = 0, shard_world = 1;
   bool ham_set = false;
   DevBuf<uint32_t> d_gx, d_term_z;
-  DevBuf<int64_t> d_tab_r, d_tab_i;
-  DevBuf<double> d_tables, d_term_cr, d_term_ci;
+  DevBuf<double> d_term_cr, d_term_ci, d_tables;
+  DevBuf<int32_t> d_tab_r, d_tab_i;
   DevBuf<int32_t> d_term_off;
   HamDev ham{};
   NoiseCfg noise{0.0, 0.0, 0ull, 0ull};
@@ -125,52 +125,68 @@ std::vector<int> assign_groups(const std::vector<uint32_t>& gx, const std::vecto
 // Build (or rebuild after re-sharding) the device Hamiltonian.
 int build_hamiltonian(vqe_t* h) {
   const int n = h->n;
-  const size_t dim = (size_t)1 << n;
   const std::vector<int> owner = assign_groups(h->gx_all, h->group_terms, h->lds_path, h->shard_world);
   std::vector<int> mine;
   for (size_t g = 0; g < owner.size(); ++g) if (owner[g] == h->shard_rank) mine.push_back((int)g);
   std::sort(mine.begin(), mine.end());
 
   std::vector<uint32_t> gx;
-  std::vector<int64_t> tab_r, tab_i;
-  std::vector<double> tables;
   std::vector<int32_t> term_off{0};
   std::vector<uint32_t> term_z;
   std::vector<double> term_cr, term_ci;
+  const size_t dim = (size_t)1 << n;
+  std::vector<int32_t> tab_r, tab_i;
+  std::vector<double> tables;
+  // LDS-path order: diagonal group first, then real-table groups (padded with zero-table
+  // dummy groups to a multiple of kEnergyPD), then groups that also need an imaginary table.
+  auto group_has_im = [&](int g) {
+    for (int k : h->group_terms[g]) if (h->hci[k] != 0.0) return true;
+    return false;
+  };
+  auto rank_of = [&](int g) { return h->gx_all[g] == 0 && !group_has_im(g) ? 0 : (group_has_im(g) ? 2 : 1); };
+  if (h->lds_path) std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return rank_of(a) < rank_of(b); });
+  int has_diag = 0, n_real = 0;
+  auto add_dummy = [&]() {
+    gx.push_back(1u);
+    term_off.push_back((int32_t)term_z.size());
+    tab_r.push_back((int32_t)tables.size());
+    tab_i.push_back(-1);
+    tables.resize(tables.size() + dim / 2 + 1, 0.0);
+  };
+  bool padded = false;
   for (int g : mine) {
     const uint32_t x = h->gx_all[g];
+    const bool has_im = group_has_im(g);
+    if (h->lds_path && !padded && (has_im)) {          // close the real section
+      while (n_real % kEnergyPD) { add_dummy(); ++n_real; }
+      padded = true;
+    }
     gx.push_back(x);
-    bool has_im = false;
     for (int k : h->group_terms[g]) {
       term_z.push_back((uint32_t)h->hz[k]);
       term_cr.push_back(h->hcr[k]);
       term_ci.push_back(h->hci[k]);
-      if (h->hci[k] != 0.0) has_im = true;
     }
     term_off.push_back((int32_t)term_z.size());
     if (h->lds_path) {
+      if (x == 0 && !has_im) has_diag = 1; else if (!has_im) ++n_real;
       const size_t len = x == 0 ? dim : dim / 2;
       const int hb = x == 0 ? 0 : 31 - __builtin_clz(x);
-      tab_r.push_back((int64_t)tables.size());
+      if (tables.size() + 2 * len > 0x7FFFFFFFu) return fail(h, VQE_EINVAL, "Hamiltonian too large for the LDS-resident path");
+      tab_r.push_back((int32_t)tables.size());
       tables.resize(tables.size() + len, 0.0);
+      if (has_im) { tab_i.push_back((int32_t)tables.size()); tables.resize(tables.size() + len, 0.0); }
+      else tab_i.push_back(-1);
       double* tr = tables.data() + tab_r.back();
-      double* ti = nullptr;
-      if (has_im) {
-        tab_i.push_back((int64_t)tables.size());
-        tables.resize(tables.size() + len, 0.0);
-        tr = tables.data() + tab_r.back();
-        ti = tables.data() + tab_i.back();
-      } else {
-        tab_i.push_back(-1);
-      }
+      double* ti = has_im ? tables.data() + tab_i.back() : nullptr;
       for (int k : h->group_terms[g]) {
         const uint32_t z = (uint32_t)h->hz[k];
         for (size_t q = 0; q < len; ++q) {
           const uint32_t p = x == 0 ? (uint32_t)q
                                     : (uint32_t)(((q >> hb) << (hb + 1)) | (q & (((size_t)1 << hb) - 1)));
-          const double s = (__builtin_popcount(p & z) & 1) ? -1.0 : 1.0;
-          tr[q] += s * h->hcr[k];
-          if (ti) ti[q] += s * h->hci[k];
+          const double sgn = (__builtin_popcount(p & z) & 1) ? -1.0 : 1.0;
+          tr[q] += sgn * h->hcr[k];
+          if (ti) ti[q] += sgn * h->hci[k];
         }
       }
     } else {
@@ -178,6 +194,8 @@ int build_hamiltonian(vqe_t* h) {
       tab_i.push_back(has_im ? 0 : -1);
     }
   }
+  if (h->lds_path && !padded)
+    while (n_real % kEnergyPD) { add_dummy(); ++n_real; }
   int rc;
   if ((rc = upload(h, h->d_gx, gx.data(), gx.size()))) return rc;
   if ((rc = upload(h, h->d_tab_r, tab_r.data(), tab_r.size()))) return rc;
@@ -194,6 +212,8 @@ int build_hamiltonian(vqe_t* h) {
   h->ham.tab_r = h->d_tab_r.p;
   h->ham.tab_i = h->d_tab_i.p;
   h->ham.tables = h->d_tables.p;
+  h->ham.has_diag = has_diag;
+  h->ham.n_real = n_real;
   h->ham.term_off = h->d_term_off.p;
   h->ham.term_z = h->d_term_z.p;
   h->ham.term_cr = h->d_term_cr.p;

@@ -11,8 +11,9 @@
 //    the end of the circuit restores the logical layout;
 //  * <psi|H|psi> is evaluated per X-mask group against precomputed sign-sum tables
 //    D_x(p) = sum_k c_k (-1)^{popc(p & z_k)} (state independent, built once per
-//    Hamiltonian), using the p <-> p^x pair symmetry, with one block reduction per
-//    evaluation;
+//    Hamiltonian, L2 resident), using the p <-> p^x pair symmetry; table values stream
+//    through a 4-group-deep register ring so that L2 latency is hidden; one block reduction
+//    per evaluation;
 //  * the COBYLA loop of the reference (scipy, sequential callbacks) runs inside the same
 //    workgroup (cobyla_m0.h), so an environment step is ONE kernel launch for all
 //    environments and there is no host round trip per evaluation.
@@ -35,9 +36,12 @@ struct Op { uint32_t xm, zm; int32_t pidx; int32_t kind; };  // kind | (inv << 8
 struct HamDev {
   int n_groups;             // X-mask groups evaluated by this handle (after sharding)
   const uint32_t* gx;       // [n_groups] X mask
-  const int64_t* tab_r;     // [n_groups] offset of the real sign-sum table (doubles)
-  const int64_t* tab_i;     // [n_groups] offset of the imaginary table or -1
-  const double* tables;     // LDS path: pair-compacted tables
+  // LDS path (n <= 13): pair-compacted sign-sum tables (diagonal group, if any, first)
+  const int32_t* tab_r;     // [n_groups] offset of the real table (doubles)
+  const int32_t* tab_i;     // [n_groups] offset of the imaginary table or -1
+  const double* tables;
+  int has_diag;             // 1: group 0 is the diagonal (x == 0) group
+  int n_real;               // real-table pair groups incl. zero padding (multiple of kEnergyPD)
   // streaming path (n >= 14): explicit terms
   int n_terms;              // terms of the groups above
   const int32_t* term_off;  // [n_groups + 1]
@@ -109,60 +113,115 @@ __device__ __forceinline__ double block_sum(double v, double* red /* >= 4 double
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Workgroup execution context of cobyla_m0.h: strided loops, block-wide reductions.  Sums
+// are taken in a different order than on the host (same algorithm, results differ in the
+// last bits).
 struct DevCtx {
   int tid;
+  double* red;   // >= 8 doubles of LDS
   static constexpr int nth = kThreads;
   __device__ void sync() const { __syncthreads(); }
   __device__ int all_or(int v) const { return __syncthreads_or(v); }
+  template <class F>
+  __device__ double sum(int n, F f) const {
+    double a = 0.0;
+    for (int i = tid; i < n; i += kThreads) a += f(i);
+    return block_sum(a, red);
+  }
+  template <class F>
+  __device__ int arg_first(int n, F f, double thresh, bool want_max, double* val) const {
+    double best = thresh;
+    int idx = 0x7fffffff;
+    for (int i = tid; i < n; i += kThreads) {
+      const double v = f(i);
+      if (want_max ? (v > best) : (v < best)) { best = v; idx = i; }
+    }
+    auto merge = [&](double ob, int oi) {
+      const bool better = want_max ? (ob > best) : (ob < best);
+      if (better || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    };
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      merge(ob, oi);
+    }
+    int* ired = (int*)(red + 4);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = best; ired[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    best = red[0]; idx = ired[0];
+#pragma unroll
+    for (int wv = 1; wv < 4; ++wv) merge(red[wv], ired[wv]);
+    *val = best;
+    return idx == 0x7fffffff ? -1 : idx;
+  }
 };
 
 // LDS carve-up of one workgroup.
-struct GroupMeta { uint32_t x; int32_t hb; int32_t off_r; int32_t off_i; };
 
+struct GroupMeta { uint32_t x; int32_t hb; int32_t off_r; int32_t off_i; };
+struct LayoutRec;
 struct Lds {
   double2* psi;     // [2^n]  (also: gate staging during compile, COBYLA matrices during tell)
-  Op* ops;          // [max_ops]
+  Op* ops;          // [max_ops] raw ops
+  Op* sched;        // [2*max_ops+2] scheduled ops (register path, n >= 10)
+  LayoutRec* lay;   // [max_ops+2] layouts (register path)
   double2* cs;      // [max_params] (cos, sin)(theta/2)
   GroupMeta* gm;    // [n_groups]
   double* red;      // [8]
   uint32_t* xm;     // [32] columns of A^-1
   uint32_t* zm;     // [32] rows of A
-  int32_t* meta;    // [8]: n_ops, offset c, phase power, permuted flag
+  int32_t* meta;    // [8]: n_ops, offset c, phase power, permuted flag, n_sched, n_layouts
+  uint32_t* sb;     // [16] scheduler scratch
 };
 
+// n >= 10: the raw ops only live while the schedule is built, in the (idle) state region.
 __host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params, int n_groups) {
-  return ((size_t)16 << n) + (size_t)16 * max_ops + (size_t)16 * max_params +
-         (size_t)16 * (n_groups > 0 ? n_groups : 1) + 64 + 128 + 128 + 32;
+  const int ng = n_groups > 0 ? n_groups : 1;
+  size_t b = (size_t)16 << n;
+  b += n >= 10 ? (size_t)16 * (2 * max_ops + 2) + (size_t)32 * (max_ops + 2) : (size_t)16 * max_ops;
+  b += (size_t)16 * max_params + (size_t)16 * ng;
+  return b + 64 + 128 + 128 + 32 + 64;
 }
 
 __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, int max_params, int n_groups) {
+  const int ng = n_groups > 0 ? n_groups : 1;
   Lds l;
   l.psi = (double2*)base; base += (size_t)16 << n;
-  l.ops = (Op*)base; base += (size_t)16 * max_ops;
+  if (n >= 10) {
+    l.ops = (Op*)(l.psi) + (((size_t)1 << n) / 2);      // upper half of the state region
+    l.sched = (Op*)base; base += (size_t)16 * (2 * max_ops + 2);
+    l.lay = (LayoutRec*)base; base += (size_t)32 * (max_ops + 2);
+  } else {
+    l.ops = (Op*)base; base += (size_t)16 * max_ops;
+    l.sched = l.ops; l.lay = (LayoutRec*)l.ops;
+  }
   l.cs = (double2*)base; base += (size_t)16 * max_params;
-  l.gm = (GroupMeta*)base; base += (size_t)16 * (n_groups > 0 ? n_groups : 1);
+  l.gm = (GroupMeta*)base; base += (size_t)16 * ng;
   l.red = (double*)base; base += 64;
   l.xm = (uint32_t*)base; base += 128;
   l.zm = (uint32_t*)base; base += 128;
-  l.meta = (int32_t*)base;
+  l.meta = (int32_t*)base; base += 32;
+  l.sb = (uint32_t*)base;
   return l;
 }
 
 // Once per kernel: X-mask group descriptors into LDS (no dependent global loads later).
-__device__ inline void stage_groups(const HamDev& H, const Lds& L) {
+__device__ __forceinline__ void stage_groups(const HamDev& H, const Lds& L) {
   for (int g = threadIdx.x; g < H.n_groups; g += kThreads) {
     const uint32_t x = H.gx[g];
-    L.gm[g] = GroupMeta{x, x ? 31 - __clz((int)x) : 0, (int32_t)H.tab_r[g], (int32_t)H.tab_i[g]};
+    L.gm[g] = GroupMeta{x, x ? 31 - __clz((int)x) : 0, H.tab_r[g], H.tab_i[g]};
   }
 }
 
 // Translate the gate list of problem b into pair-exchange ops (CNOT / Pauli-X become
 // updates of the affine map).  All threads stage the gate records into the (idle) state
 // region, thread 0 walks them.  Noise Paulis are drawn per evaluation.  Ends with a barrier.
-__device__ inline void compile_ops(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip = -1) {
+__device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip = -1) {
   const int n = A.n;
   const int G = A.gate_count[b];
-  const int cap = (int)(((size_t)16 << n) / sizeof(GateRec));
+  const int cap = (int)(((size_t)16 << n) / sizeof(GateRec)) / (n >= 10 ? 2 : 1);
   const GateRec* gsrc = A.gates + A.gate_begin[b];
   GateRec* gl = (GateRec*)L.psi;
   const bool staged = G <= cap;
@@ -229,11 +288,25 @@ __device__ inline void compile_ops(const BatchArgs& A, int b, uint64_t eval_id, 
   __syncthreads();
 }
 
+}  // namespace vqe
+#include "vqe_reg.h"
+namespace vqe {
+
+// compile + (n >= 10) schedule for the register-resident path; ends with a barrier
+template <int N>
+__device__ __forceinline__ void compile_all(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip = -1) {
+  compile_ops(A, b, eval_id, L, skip);
+  if constexpr (N >= kRegMinQubits) {
+    if (threadIdx.x == 0) schedule_ops<N>(L);
+    __syncthreads();
+  }
+}
+
 // Apply the compiled ops to the LDS-resident state, then restore the logical layout.
 // `theta` holds the P parameters of the circuit, or - when p_hole >= 0 - the P-1 parameters
 // of the circuit without the rotation whose parameter index is p_hole.
 template <int N>
-__device__ inline void run_ops(const Lds& L, const double* theta, int P, int p_hole = -1) {
+__device__ __forceinline__ void run_ops(const Lds& L, const double* theta, int P, int p_hole = -1) {
   constexpr uint32_t DIM = 1u << N;
   constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;   // pairs per thread
   constexpr int NA = (DIM + kThreads - 1) / kThreads;       // amplitudes per thread
@@ -324,7 +397,7 @@ __device__ inline void run_ops(const Lds& L, const double* theta, int P, int p_h
 }
 
 template <int N>
-__device__ inline void load_init(const Lds& L, const double2* init) {
+__device__ __forceinline__ void load_init(const Lds& L, const double2* init) {
   constexpr uint32_t DIM = 1u << N;
   constexpr int NA = (DIM + kThreads - 1) / kThreads;
 #pragma unroll
@@ -335,82 +408,121 @@ __device__ inline void load_init(const Lds& L, const double2* init) {
 }
 
 // <psi|H|psi> over this handle's X-mask groups; identical result in every thread.
-// Sign-sum tables stream from L2 one group ahead of the LDS pair reads that consume them.
-template <int N>
-__device__ inline double lds_energy(const Lds& L, const HamDev& H) {
-  constexpr uint32_t DIM = 1u << N;
-  constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;
-  const int tid = threadIdx.x;
-  const double* __restrict__ tables = H.tables;
-  double acc = 0.0;
-  const int ng = H.n_groups;
-  double cur[NP], nxt[NP];
-  auto fetch = [&](int g, double* dst) {
-    const GroupMeta m = L.gm[g];
-    const double* t = tables + m.off_r;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const uint32_t q = tid + k * kThreads;
-      dst[k] = (DIM / 2 >= kThreads || q < DIM / 2) ? t[q] : 0.0;
-    }
-  };
-  if (ng > 0) fetch(0, cur);
-  for (int g = 0; g < ng; ++g) {
-    const GroupMeta m = L.gm[g];
-    if (g + 1 < ng) fetch(g + 1, nxt);
-    if (m.x == 0) {
-      // diagonal group: full-length table; second half fetched here
-      const double* t = tables + m.off_r;
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        const uint32_t p = tid + k * kThreads;
-        if (DIM / 2 >= kThreads || p < DIM / 2) {
-          const double2 a = L.psi[p];
-          acc += (a.x * a.x + a.y * a.y) * cur[k];
-          const uint32_t p2 = p + DIM / 2;
-          const double2 a2 = L.psi[p2];
-          acc += (a2.x * a2.x + a2.y * a2.y) * t[p2];
-        }
-      }
-    } else {
-      double part = 0.0;
-      if (m.off_i < 0) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          const uint32_t q = tid + k * kThreads;
-          if (DIM / 2 >= kThreads || q < DIM / 2) {
-            const uint32_t p0 = insert0(q, m.hb);
-            const double2 b = L.psi[p0], a = L.psi[p0 ^ m.x];
-            part += (a.x * b.x + a.y * b.y) * cur[k];
-          }
-        }
-      } else {
-        const double* ti = tables + m.off_i;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          const uint32_t q = tid + k * kThreads;
-          if (DIM / 2 >= kThreads || q < DIM / 2) {
-            const uint32_t p0 = insert0(q, m.hb);
-            const double2 b = L.psi[p0], a = L.psi[p0 ^ m.x];
-            part += (a.x * b.x + a.y * b.y) * cur[k] - (a.x * b.y - a.y * b.x) * ti[q];
-          }
-        }
-      }
-      acc += 2.0 * part;
-    }
-#pragma unroll
-    for (int k = 0; k < NP; ++k) cur[k] = nxt[k];
-  }
-  return block_sum(acc, L.red);
-}
+// Group order (host): [diagonal] [real-table groups, padded with zero-table dummies to a
+// multiple of PD] [groups with an imaginary table].  Table values stream from L2 through a
+// PD-deep register ring (group g+PD is requested when group g is consumed); the PD-unrolled
+// body is branch free so LDS reads of one group overlap the FMAs of the previous one.
+constexpr int kEnergyPD = 4;
 
 template <int N>
-__device__ inline double lds_evaluate(const BatchArgs& A, int b, const Lds& L, const double* theta,
-                                      int P, bool noisy, uint64_t eval_id, int skip = -1, int p_hole = -1) {
-  if (noisy) compile_ops(A, b, eval_id, L, skip);
-  load_init<N>(L, A.init);
-  __syncthreads();
-  run_ops<N>(L, theta, P, p_hole);
+__device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
+  constexpr uint32_t DIM = 1u << N;
+  constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;   // pairs per thread
+  constexpr int KB = N > 9 ? N - 9 : 0;                     // log2(NP)
+  constexpr int PD = kEnergyPD;
+  constexpr bool FULL = DIM / 2 >= kThreads;                // every thread owns NP pairs
+  const uint32_t tid = threadIdx.x;
+  const double* __restrict__ tables = H.tables;
+  double acc0 = 0.0, acc1 = 0.0;
+  int g0 = 0;
+  if (H.has_diag) {   // diagonal group: full-length table
+    const double* t = tables + L.gm[0].off_r;
+    constexpr int NA = (DIM + kThreads - 1) / kThreads;
+    double dv[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const uint32_t p = tid + (uint32_t)k * kThreads;
+      dv[k] = (DIM >= kThreads || p < DIM) ? t[p] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const uint32_t p = tid + (uint32_t)k * kThreads;
+      if (DIM >= kThreads || p < DIM) {
+        const double2 a = L.psi[p];
+        acc0 += (a.x * a.x + a.y * a.y) * dv[k];
+      }
+    }
+    g0 = 1;
+  }
+  const int g1 = g0 + H.n_real;        // multiple of PD groups with real tables
+  double buf[PD][NP];
+  auto fetch = [&](int g, double (&dst)[NP]) {
+    const double* t = tables + __builtin_amdgcn_readfirstlane(L.gm[g].off_r);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const uint32_t q = tid + (uint32_t)k * kThreads;
+      dst[k] = (FULL || q < DIM / 2) ? t[q] : 0.0;
+    }
+  };
+  auto consume = [&](int g, const double (&d)[NP]) {
+    const GroupMeta m = L.gm[g];
+    const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.x);
+    const int hb = __builtin_amdgcn_readfirstlane(m.hb);
+    const uint32_t base = insert0(tid, hb), basex = base ^ x;
+    uint32_t kbit[KB > 0 ? KB : 1];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) kbit[i] = 1u << (8 + i + ((8 + i) >= hb ? 1 : 0));
+    double p0s = 0.0, p1s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      uint32_t kc = 0;
+#pragma unroll
+      for (int i = 0; i < KB; ++i) if ((k >> i) & 1) kc ^= kbit[i];
+      if (FULL || tid + (uint32_t)k * kThreads < DIM / 2) {
+        const double2 b = L.psi[base ^ kc], a = L.psi[basex ^ kc];
+        const double v = (a.x * b.x + a.y * b.y) * d[k];
+        if (k & 1) p1s += v; else p0s += v;
+      }
+    }
+    acc0 += 2.0 * p0s;
+    acc1 += 2.0 * p1s;
+  };
+  if (g0 < g1) {
+#pragma unroll
+    for (int j = 0; j < PD; ++j) fetch(g0 + j, buf[j]);
+    for (int g = g0; g < g1; g += PD) {
+      const int gn = g + PD < g1 ? g + PD : g;   // last round re-fetches its own (harmless)
+#pragma unroll
+      for (int j = 0; j < PD; ++j) {
+        consume(g + j, buf[j]);
+        fetch(gn + j, buf[j]);
+        // keep the scheduler from hoisting the LDS reads of all PD groups to the top of the
+        // unrolled body (that costs > 256 VGPRs and the second workgroup per CU)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // groups with imaginary parts (odd number of Y factors): rare, plain loop
+  for (int g = g1; g < H.n_groups; ++g) {
+    const GroupMeta m = L.gm[g];
+    const double* tr = tables + m.off_r;
+    const double* ti = tables + m.off_i;
+    double part = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const uint32_t q = tid + (uint32_t)k * kThreads;
+      if (FULL || q < DIM / 2) {
+        const uint32_t p0 = insert0(q, m.hb);
+        const double2 b = L.psi[p0], a = L.psi[p0 ^ m.x];
+        part += (a.x * b.x + a.y * b.y) * tr[q] - (a.x * b.y - a.y * b.x) * ti[q];
+      }
+    }
+    acc0 += 2.0 * part;
+  }
+  return block_sum(acc0 + acc1, L.red);
+}
+
+// One evaluation with the ops already compiled: circuit, then <psi|H|psi>.
+template <int N>
+__device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L, const double* theta, int P,
+                                               int p_hole = -1) {
+  if constexpr (N >= kRegMinQubits) {
+    run_ops_reg<N>(L, A.init, theta, P, p_hole);
+  } else {
+    load_init<N>(L, A.init);
+    __syncthreads();
+    run_ops<N>(L, theta, P, p_hole);
+  }
   return lds_energy<N>(L, A.ham);
 }
 
@@ -429,6 +541,7 @@ struct StagedCobyla {
     words = (int)cby::scratch_doubles(n);
     staged = (size_t)words * 8 <= ((size_t)16 << N);
     cob.ctx.tid = threadIdx.x;
+    cob.ctx.red = L.red;
     cob.bind(gmem, n);
   }
   __device__ void in() {
@@ -470,10 +583,8 @@ __global__ void __launch_bounds__(kThreads) k_lds_energy(BatchArgs A) {
   const int b = blockIdx.x;
   const bool noisy = (A.noise.p1 > 0.0 || A.noise.p2 > 0.0);
   stage_groups(A.ham, L);
-  if (!noisy) compile_ops(A, b, 0, L);
-  __syncthreads();
-  const double e = lds_evaluate<N>(A, b, L, A.theta + A.par_begin[b], A.par_count[b], noisy,
-                                   A.noise.eval_base);
+  compile_all<N>(A, b, noisy ? A.noise.eval_base : 0, L);
+  const double e = lds_evaluate<N>(A, L, A.theta + A.par_begin[b], A.par_count[b]);
   if (threadIdx.x == 0) { A.fout[b] = e; if (A.nfev) A.nfev[b] = 1; }
 }
 
@@ -481,10 +592,14 @@ template <int N>
 __global__ void __launch_bounds__(kThreads) k_lds_state(BatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
-  compile_ops(A, 0, A.noise.eval_base, L);
-  load_init<N>(L, A.init);
-  __syncthreads();
-  run_ops<N>(L, A.theta + A.par_begin[0], A.par_count[0]);
+  compile_all<N>(A, 0, A.noise.eval_base, L);
+  if constexpr (N >= kRegMinQubits) {
+    run_ops_reg<N>(L, A.init, A.theta + A.par_begin[0], A.par_count[0]);
+  } else {
+    load_init<N>(L, A.init);
+    __syncthreads();
+    run_ops<N>(L, A.theta + A.par_begin[0], A.par_count[0]);
+  }
   const int ph = L.meta[2];
   for (uint32_t p = threadIdx.x; p < (1u << N); p += kThreads) {
     double2 a = L.psi[p];
@@ -504,7 +619,7 @@ __global__ void __launch_bounds__(kThreads) k_lds_state(BatchArgs A) {
 // variable), and with env_step = 1 the optimum is rounded to float32 (the state tensor's
 // dtype, :480) and the energy of the FULL circuit is reported (:291).
 template <int N>
-__global__ void __launch_bounds__(kThreads) k_lds_minimize(BatchArgs A) {
+__global__ void __launch_bounds__(kThreads, (N <= 12 ? 2 : 1)) k_lds_minimize(BatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
   const int b = blockIdx.x;
@@ -520,40 +635,59 @@ __global__ void __launch_bounds__(kThreads) k_lds_minimize(BatchArgs A) {
   }
   const int Popt = P - (p_hole >= 0);
   stage_groups(A.ham, L);
-  if (!noisy) compile_ops(A, b, 0, L, skip);
-  __syncthreads();
-  int nfev = 1;
-  double fret;
-  if (Popt == 0) {  // scipy returns after a single evaluation for an empty x0
-    fret = lds_evaluate<N>(A, b, L, theta, P, noisy, A.noise.eval_base, skip, p_hole);
-    for (int j = threadIdx.x; j < P; j += kThreads) { xout[j] = theta[j]; A.xraw[A.par_begin[b] + j] = theta[j]; }
-  } else {
-    StagedCobyla<N> sc;
+  StagedCobyla<N> sc;
+  cby::CobylaM0<DevCtx>& cob = sc.cob;
+  // phases: 0 = single evaluation (empty x0: scipy returns after one call), 1 = COBYLA loop,
+  // 2 = post-action evaluation of env_step.  ONE evaluation call site keeps everything inlined.
+  int phase = 0, nfev = 1;
+  bool need_compile = true;
+  double fret = 0.0, flast = 0.0;
+  if (Popt > 0) {
     sc.init(A.scratch + A.scratch_begin[b], L, Popt);
-    cby::CobylaM0<DevCtx>& cob = sc.cob;
     for (int j = threadIdx.x; j < P; j += kThreads)
       if (j != p_hole) cob.x[j - (p_hole >= 0 && j > p_hole)] = theta[j];
     __syncthreads();
-    int want = sc.start(A.rhobeg, A.rhoend, A.maxfun);
-    double flast = 0.0;
-    while (want) {
-      flast = lds_evaluate<N>(A, b, L, cob.x, P, noisy, A.noise.eval_base + (uint64_t)cob.nfvals, skip, p_hole);
-      want = sc.tell(flast);
-    }
-    for (int j = threadIdx.x; j < P; j += kThreads) {
-      const double v = (j == p_hole) ? theta[j] : cob.x[j - (p_hole >= 0 && j > p_hole)];
-      xout[j] = A.env_step ? (double)(float)v : v;
-      A.xraw[A.par_begin[b] + j] = v;
-    }
-    fret = (cob.status == cby::DONE_RHOEND && cob.ifull == 1) ? flast : cob.fbest_ret;
-    nfev = cob.nfvals;
+    sc.start(A.rhobeg, A.rhoend, A.maxfun);   // always asks for f(x0)
+    phase = 1;
   }
-  if (A.env_step) {
-    __syncthreads();
-    if (Popt == 0)
-      for (int j = threadIdx.x; j < P; j += kThreads) xout[j] = (double)(float)theta[j];
-    if (!noisy) compile_ops(A, b, 0, L, -1);
-    fret = lds_evaluate<N>(A, b, L, xout, P, noisy, A.noise.eval_base + (uint64_t)A.maxfun + 1, -1, -1);
+  for (;;) {
+    const double* th = phase == 0 ? theta : (phase == 1 ? cob.x : xout);
+    const int sk = phase == 2 ? -1 : skip;
+    const int ph = phase == 2 ? -1 : p_hole;
+    const uint64_t eid = A.noise.eval_base +
+                         (phase == 1 ? (uint64_t)cob.nfvals : (phase == 2 ? (uint64_t)A.maxfun + 1 : 0));
+    if (noisy || need_compile) { compile_all<N>(A, b, noisy ? eid : 0, L, sk); need_compile = false; }
+    const double e = lds_evaluate<N>(A, L, th, P, ph);
+    bool finished_opt = false;
+    if (phase == 0) {
+      fret = e;
+      for (int j = threadIdx.x; j < P; j += kThreads) {
+        xout[j] = A.env_step ? (double)(float)theta[j] : theta[j];
+        A.xraw[A.par_begin[b] + j] = theta[j];
+      }
+      finished_opt = true;
+    } else if (phase == 1) {
+      flast = e;
+      if (!sc.tell(e)) {
+        for (int j = threadIdx.x; j < P; j += kThreads) {
+          const double v = (j == p_hole) ? theta[j] : cob.x[j - (p_hole >= 0 && j > p_hole)];
+          xout[j] = A.env_step ? (double)(float)v : v;
+          A.xraw[A.par_begin[b] + j] = v;
+        }
+        fret = (cob.status == cby::DONE_RHOEND && cob.ifull == 1) ? flast : cob.fbest_ret;
+        nfev = cob.nfvals;
+        finished_opt = true;
+      }
+    } else {
+      fret = e;
+      break;
+    }
+    if (finished_opt) {
+      if (!A.env_step) break;
+      __syncthreads();          // xout visible to the whole workgroup
+      phase = 2;
+      need_compile = true;      // the full circuit, including the new gate
+    }
   }
   if (threadIdx.x == 0) { A.fout[b] = fret; A.nfev[b] = nfev; }
 }

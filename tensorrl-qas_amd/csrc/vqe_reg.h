@@ -1,0 +1,273 @@
+// vqe_reg.h - register-resident circuit application for 10 <= n <= 13 (included by
+// vqe_device.h).
+//
+// Every thread keeps NA = 2^(n-8) amplitudes in VGPRs.  A *layout* is a basis of GF(2)^n
+// split into R = n-8 "register directions" e_0..e_{R-1} (fully reduced echelon form, pivot =
+// highest set bit) and 8 unit vectors on the non-pivot bit positions that are addressed by
+// the thread id:   physical index (tid, r) = deposit(tid -> non-pivot bits) ^ XOR_{i in r} e_i.
+//
+// A rotation whose pair mask xm lies in span(e) pairs register r with register r ^ j
+// (j = coordinates of xm), entirely inside the thread: no LDS traffic, no barrier.  RZ and
+// Pauli-Z are diagonal and always local.  Thread 0 schedules the circuit greedily: when a
+// mask falls outside the current span it opens a new layout whose register directions are
+// the next R independent masks of the circuit, and the workgroup re-distributes the state
+// through LDS once (write 16 B * 2^n, barrier, read).  LDS bandwidth - the limiter of the
+// plain LDS-state version (ds_write_b128 ~79 B/clk/CU) - is then paid once per layout
+// (~4 two-level rotations + all diagonal ones) instead of once per rotation.  After the last
+// op every thread scatters its amplitudes to LDS in LOGICAL order for the energy phase.
+#pragma once
+
+namespace vqe {
+
+constexpr int kRegMinQubits = 10;
+enum : int { OP_RELAYOUT = 5 };
+
+struct LayoutRec {  // 32 bytes
+  uint32_t e[5];     // register directions (reduced echelon form)
+  uint32_t pos;      // 8 x 4 bits: non-pivot bit positions, ascending
+  uint32_t pad[2];
+};
+
+// ---- scheduler (thread 0) ---------------------------------------------------------------------
+struct Basis {           // storage lives in LDS (runtime-indexed arrays would land in scratch)
+  uint32_t* e;           // [5]
+  int32_t* piv;          // [5]
+  int k;
+  __device__ void clear() { k = 0; }
+  __device__ uint32_t reduce(uint32_t v) const {
+    for (int i = 0; i < k; ++i) if ((v >> piv[i]) & 1u) v ^= e[i];
+    return v;
+  }
+  __device__ bool add(uint32_t v) {      // keeps the basis fully reduced
+    v = reduce(v);
+    if (!v) return false;
+    const int p = 31 - __clz((int)v);
+    for (int i = 0; i < k; ++i) if ((e[i] >> p) & 1u) e[i] ^= v;
+    e[k] = v; piv[k] = p; ++k;
+    return true;
+  }
+  __device__ uint32_t coords(uint32_t v) const {   // v must be in the span
+    uint32_t j = 0;
+    for (int i = 0; i < k; ++i) j |= ((v >> piv[i]) & 1u) << i;
+    return j;
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void emit_layout(const Basis& B, LayoutRec* out) {
+  uint32_t pivmask = 0;
+  for (int i = 0; i < 5; ++i) out->e[i] = i < B.k ? B.e[i] : 0u;
+  for (int i = 0; i < B.k; ++i) pivmask |= 1u << B.piv[i];
+  uint32_t pos = 0;
+  int cnt = 0;
+  for (int b = 0; b < N; ++b)
+    if (!((pivmask >> b) & 1u)) { pos |= (uint32_t)b << (4 * cnt); ++cnt; }
+  out->pos = pos;
+}
+
+// raw ops (L.ops, n = meta[0]) -> scheduled ops (L.sched, n = meta[4]) + layouts (L.lay)
+template <int N>
+__device__ __forceinline__ void schedule_ops(const Lds& L) {
+  constexpr int R = N - 8;
+  const int nraw = L.meta[0];
+  int ns = 0, nl = 0;
+  Basis B;
+  B.e = (uint32_t*)L.sb;
+  B.piv = (int32_t*)L.sb + 8;
+  auto open_layout = [&](int from) {
+    B.clear();
+    for (int k = from; k < nraw && B.k < R; ++k) {
+      const int kd = L.ops[k].kind & 0xff;
+      if (kd == OP_RX || kd == OP_RY) B.add(L.ops[k].xm);
+    }
+    for (int b = N - 1; b >= 0 && B.k < R; --b) B.add(1u << b);   // fill with unit directions
+    emit_layout<N>(B, &L.lay[nl]);
+    ++nl;
+  };
+  open_layout(0);
+  for (int o = 0; o < nraw; ++o) {
+    const Op op = L.ops[o];
+    const int kd = op.kind & 0xff;
+    uint32_t j = 0;
+    if (kd == OP_RX || kd == OP_RY) {
+      if (B.reduce(op.xm) != 0) {
+        open_layout(o);
+        L.sched[ns++] = Op{(uint32_t)(nl - 1), 0u, -1, OP_RELAYOUT};
+      }
+      j = B.coords(op.xm);
+    }
+    uint32_t svec = 0;
+    for (int i = 0; i < R; ++i) svec |= (uint32_t)parity32(op.zm & B.e[i]) << i;
+    L.sched[ns++] = Op{j | (svec << 8), op.zm, op.pidx, op.kind};
+  }
+  L.meta[4] = ns;
+  L.meta[5] = nl;
+}
+
+// ---- per-thread helpers -----------------------------------------------------------------------
+__device__ __forceinline__ uint32_t deposit8(uint32_t tid, uint32_t pos) {
+  uint32_t b = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b |= ((tid >> j) & 1u) << ((pos >> (4 * j)) & 15u);
+  return b;
+}
+
+template <int R>
+__device__ __forceinline__ uint32_t combo(const uint32_t (&e)[5], int r) {
+  uint32_t v = 0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) if ((r >> i) & 1) v ^= e[i];
+  return v;
+}
+
+// bit r of the result = parity(r & svec)
+template <int R>
+__device__ __forceinline__ uint32_t sign_word(uint32_t svec) {
+  constexpr uint32_t pat[5] = {0xAAAAAAAAu, 0xCCCCCCCCu, 0xF0F0F0F0u, 0xFF00FF00u, 0xFFFF0000u};
+  uint32_t w = 0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) if ((svec >> i) & 1u) w ^= pat[i];
+  return w;
+}
+
+__device__ __forceinline__ double flip_if(double v, uint32_t w, int r) {
+  // v with its sign flipped iff bit r of w is set
+  const uint32_t hi = (uint32_t)__double2hiint(v) ^ (((w >> r) & 1u) << 31);
+  return __hiloint2double((int)hi, __double2loint(v));
+}
+
+template <int NA, int J>
+__device__ __forceinline__ void rx_pairs(double2 (&amp)[NA], double c, double s) {
+  static_assert(J > 0 && J < NA, "partner mask out of range");
+  constexpr int HB = 31 - __builtin_clz(J);
+#pragma unroll
+  for (int r = 0; r < NA; ++r) {
+    if ((r >> HB) & 1) continue;
+    const int r2 = r ^ J;
+    const double2 a0 = amp[r], a1 = amp[r2];
+    amp[r] = make_double2(c * a0.x - s * a1.y, c * a0.y + s * a1.x);
+    amp[r2] = make_double2(c * a1.x - s * a0.y, c * a1.y + s * a0.x);
+  }
+}
+
+template <int NA, int J>
+__device__ __forceinline__ void ry_pairs(double2 (&amp)[NA], double c, double s, uint32_t w) {
+  constexpr int HB = 31 - __builtin_clz(J);
+#pragma unroll
+  for (int r = 0; r < NA; ++r) {
+    if ((r >> HB) & 1) continue;
+    const int r2 = r ^ J;
+    const double s0 = flip_if(s, w, r);
+    const double2 a0 = amp[r], a1 = amp[r2];
+    amp[r] = make_double2(c * a0.x + s0 * a1.x, c * a0.y + s0 * a1.y);
+    amp[r2] = make_double2(c * a1.x - s0 * a0.x, c * a1.y - s0 * a0.y);
+  }
+}
+
+// The partner-mask dispatch is a switch written INSIDE run_ops_reg (not a helper taking the
+// array by reference): a helper is optimised on its own first, where branch-merging turns the
+// per-case constant register indices into pointer PHIs and the amplitudes end up in scratch.
+#define VQE_PAIR_CASE(J, CALL) case J: if constexpr (J < NA) { CALL; } break;
+#define VQE_PAIR_SWITCH(j, F, ...)                                                                 \
+  switch (j) {                                                                                     \
+    VQE_PAIR_CASE(1, (F<NA, 1>(__VA_ARGS__))) VQE_PAIR_CASE(2, (F<NA, 2>(__VA_ARGS__)))            \
+    VQE_PAIR_CASE(3, (F<NA, 3>(__VA_ARGS__))) VQE_PAIR_CASE(4, (F<NA, 4>(__VA_ARGS__)))            \
+    VQE_PAIR_CASE(5, (F<NA, 5>(__VA_ARGS__))) VQE_PAIR_CASE(6, (F<NA, 6>(__VA_ARGS__)))            \
+    VQE_PAIR_CASE(7, (F<NA, 7>(__VA_ARGS__))) VQE_PAIR_CASE(8, (F<NA, 8>(__VA_ARGS__)))            \
+    VQE_PAIR_CASE(9, (F<NA, 9>(__VA_ARGS__))) VQE_PAIR_CASE(10, (F<NA, 10>(__VA_ARGS__)))          \
+    VQE_PAIR_CASE(11, (F<NA, 11>(__VA_ARGS__))) VQE_PAIR_CASE(12, (F<NA, 12>(__VA_ARGS__)))        \
+    VQE_PAIR_CASE(13, (F<NA, 13>(__VA_ARGS__))) VQE_PAIR_CASE(14, (F<NA, 14>(__VA_ARGS__)))        \
+    VQE_PAIR_CASE(15, (F<NA, 15>(__VA_ARGS__))) VQE_PAIR_CASE(16, (F<NA, 16>(__VA_ARGS__)))        \
+    VQE_PAIR_CASE(17, (F<NA, 17>(__VA_ARGS__))) VQE_PAIR_CASE(18, (F<NA, 18>(__VA_ARGS__)))        \
+    VQE_PAIR_CASE(19, (F<NA, 19>(__VA_ARGS__))) VQE_PAIR_CASE(20, (F<NA, 20>(__VA_ARGS__)))        \
+    VQE_PAIR_CASE(21, (F<NA, 21>(__VA_ARGS__))) VQE_PAIR_CASE(22, (F<NA, 22>(__VA_ARGS__)))        \
+    VQE_PAIR_CASE(23, (F<NA, 23>(__VA_ARGS__))) VQE_PAIR_CASE(24, (F<NA, 24>(__VA_ARGS__)))        \
+    VQE_PAIR_CASE(25, (F<NA, 25>(__VA_ARGS__))) VQE_PAIR_CASE(26, (F<NA, 26>(__VA_ARGS__)))        \
+    VQE_PAIR_CASE(27, (F<NA, 27>(__VA_ARGS__))) VQE_PAIR_CASE(28, (F<NA, 28>(__VA_ARGS__)))        \
+    VQE_PAIR_CASE(29, (F<NA, 29>(__VA_ARGS__))) VQE_PAIR_CASE(30, (F<NA, 30>(__VA_ARGS__)))        \
+    VQE_PAIR_CASE(31, (F<NA, 31>(__VA_ARGS__)))                                                    \
+    default: break;                                                                                \
+  }
+
+// Apply the scheduled ops with the amplitudes in registers; leaves the state in L.psi in
+// LOGICAL order (same contract as run_ops).
+template <int N>
+__device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restrict__ init, const double* theta, int P,
+                                   int p_hole = -1) {
+  constexpr int R = N - 8;
+  constexpr int NA = 1 << R;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < P; j += kThreads) {
+    if (j == p_hole) continue;
+    double s, c;
+    sincos(0.5 * theta[j - (p_hole >= 0 && j > p_hole)], &s, &c);
+    L.cs[j] = make_double2(c, s);
+  }
+  double2 amp[NA];
+  uint32_t e[5];
+  {
+    const LayoutRec lr = L.lay[0];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) e[i] = lr.e[i];
+    const uint32_t base0 = deposit8(tid, lr.pos);
+#pragma unroll
+    for (int r = 0; r < NA; ++r) amp[r] = init[base0 ^ combo<R>(e, r)];
+  }
+  uint32_t base = deposit8(tid, L.lay[0].pos);
+  __syncthreads();   // cs[] visible
+  const int nops = L.meta[4];
+  for (int o = 0; o < nops; ++o) {
+    const Op op = L.sched[o];
+    const int kind = op.kind & 0xff;
+    if (kind == OP_RELAYOUT) {
+      __syncthreads();                                   // earlier reads of psi are done
+#pragma unroll
+      for (int r = 0; r < NA; ++r) L.psi[base ^ combo<R>(e, r)] = amp[r];
+      const LayoutRec lr = L.lay[op.xm];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) e[i] = lr.e[i];
+      base = deposit8(tid, lr.pos);
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < NA; ++r) amp[r] = L.psi[base ^ combo<R>(e, r)];
+      continue;
+    }
+    const int inv = (op.kind >> 8) & 1;
+    const uint32_t flip = (uint32_t)(parity32(op.zm & base) ^ inv);
+    const uint32_t w = sign_word<R>(op.xm >> 8) ^ (0u - flip);
+    if (kind == OP_RX) {
+      const double2 cs = L.cs[op.pidx];
+      VQE_PAIR_SWITCH((int)(op.xm & 0xff), rx_pairs, amp, cs.x, cs.y)
+    } else if (kind == OP_RY) {
+      const double2 cs = L.cs[op.pidx];
+      VQE_PAIR_SWITCH((int)(op.xm & 0xff), ry_pairs, amp, cs.x, cs.y, w)
+    } else if (kind == OP_RZ) {
+      const double2 cs = L.cs[op.pidx];
+#pragma unroll
+      for (int r = 0; r < NA; ++r) {
+        const double s = flip_if(cs.y, w, r);
+        const double2 a = amp[r];
+        amp[r] = make_double2(cs.x * a.x - s * a.y, cs.x * a.y + s * a.x);
+      }
+    } else {  // OP_PZ
+#pragma unroll
+      for (int r = 0; r < NA; ++r) amp[r] = make_double2(flip_if(amp[r].x, w, r), flip_if(amp[r].y, w, r));
+    }
+  }
+  // scatter to logical order: i = A * p ^ c, bit q of A*p = parity(zm[q] & p)
+  uint32_t ib = (uint32_t)L.meta[1];
+  uint32_t ae[5] = {0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    const uint32_t z = L.zm[q];
+    ib ^= (uint32_t)parity32(z & base) << q;
+#pragma unroll
+    for (int i = 0; i < R; ++i) ae[i] |= (uint32_t)parity32(z & e[i]) << q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NA; ++r) L.psi[ib ^ combo<R>(ae, r)] = amp[r];
+  __syncthreads();
+}
+
+}  // namespace vqe
