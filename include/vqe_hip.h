@@ -131,6 +131,10 @@ int vqe_batch_energy_devptr(vqe_t* h, void** dev_ptr);
 /* asynchronous device-to-device copy of that array into caller-owned device memory
  * (e.g. a torch tensor) on the handle's stream */
 int vqe_batch_copy_energy(vqe_t* h, void* dst_dev /* float64[batch] */);
+/* diagnostic builds only (-DVQE_STAMPS): [0] evaluations, [1] cycles in the circuit phase,
+ * [2] in the energy phase, [3] in the optimiser update, summed over workgroups; read and
+ * cleared.  All zero in the shipped library (no stamp executes there). */
+int vqe_debug_counters(vqe_t* h, uint64_t out[8]);
 /* kernel time of the last *_run call measured with HIP events on the handle's stream */
 int vqe_last_kernel_ms(vqe_t* h, float* ms);
 

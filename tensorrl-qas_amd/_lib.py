@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvqe_hip.so")
+LIB_PATH = os.environ.get("VQE_HIP_LIB") or os.path.join(_HERE, "libvqe_hip.so")  # override for kernel experiments
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -41,6 +41,7 @@ SIGNATURES = {
     "vqe_batch_fetch_xopt": (C.c_int, [vp, c_f64p]),
     "vqe_batch_energy_devptr": (C.c_int, [vp, C.POINTER(vp)]),
     "vqe_batch_copy_energy": (C.c_int, [vp, vp]),
+    "vqe_debug_counters": (C.c_int, [vp, c_u64p]),
     "vqe_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "vqe_cobyla_create": (C.c_int, [C.c_int, c_f64p, C.c_double, C.c_double, C.c_int, C.POINTER(vp)]),
     "vqe_cobyla_ask": (C.c_int, [vp, c_f64p]),

@@ -31,6 +31,12 @@
 #define CBY_HD
 #endif
 
+// The optimiser's arithmetic is kept un-contracted (no FMA fusion): that is what makes the
+// host build reproduce scipy's iterates bit for bit.  The pragma is scoped to this header.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
 namespace cby {
 
 #if defined(__HIPCC__)
@@ -398,3 +404,7 @@ struct CobylaM0 {
 };
 
 }  // namespace cby
+
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

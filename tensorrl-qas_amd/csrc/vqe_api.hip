@@ -76,6 +76,7 @@ struct vqe_handle {
   std::vector<int32_t> h_gate_count;
   DevBuf<double> d_theta, d_x, d_xraw, d_f, d_scratch;
   DevBuf<double2> d_state;
+  DevBuf<unsigned long long> d_dbg;
   StreamWork sw;  // streaming-path work buffers
 };
 
@@ -292,6 +293,7 @@ BatchArgs make_args(vqe_t* h) {
   A.max_ops = h->max_ops;
   A.max_params = h->max_params;
   A.state_out = h->d_state.p;
+  A.dbg = h->d_dbg.p;
   return A;
 }
 
@@ -461,6 +463,10 @@ int vqe_create(int n_qubits, int device_id, vqe_t** out) {
   h->cu_count = prop.multiProcessorCount;
   h->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
   if (h->lds_per_cu <= 0) h->lds_per_cu = 65536;
+  if (h->d_dbg.reserve(8) != hipSuccess || hipMemset(h->d_dbg.p, 0, 64) != hipSuccess) {
+    delete h;
+    return fail(nullptr, VQE_ENOMEM, "device allocation failed");
+  }
   *out = h;
   int rc = vqe_set_init_state(h, nullptr);
   if (rc) { g_create_error = h->err; vqe_destroy(h); *out = nullptr; return rc; }
@@ -710,6 +716,15 @@ int vqe_batch_copy_energy(vqe_t* h, void* dst_dev) {
   if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
   HIP_TRY(h, hipSetDevice(h->dev));
   HIP_TRY(h, hipMemcpyAsync(dst_dev, h->d_f.p, (size_t)h->batch * 8, hipMemcpyDeviceToDevice, h->stream));
+  return VQE_OK;
+}
+
+int vqe_debug_counters(vqe_t* h, uint64_t out[8]) {
+  if (!h || !out) return VQE_EINVAL;
+  HIP_TRY(h, hipSetDevice(h->dev));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(out, h->d_dbg.p, 64, hipMemcpyDeviceToHost));
+  HIP_TRY(h, hipMemset(h->d_dbg.p, 0, 64));
   return VQE_OK;
 }
 

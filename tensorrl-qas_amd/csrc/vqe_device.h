@@ -77,6 +77,7 @@ struct BatchArgs {
   double rhobeg, rhoend;
   int maxfun;
   double2* state_out;          // get_state: [2^n]
+  unsigned long long* dbg;     // [8] phase cycle counters, written only by -DVQE_STAMPS builds
 };
 
 // ---------------------------------------------------------------------------------------
@@ -414,80 +415,104 @@ __device__ __forceinline__ void load_init(const Lds& L, const double2* init) {
 // body is branch free so LDS reads of one group overlap the FMAs of the previous one.
 constexpr int kEnergyPD = 4;
 
+// One pair group with the thread's own amplitudes in registers (x has a bit S+8 >= 8): the
+// "first" member of every pair is an own amplitude own[r] with bit S of r clear, only the
+// partner comes from LDS.  Expanded in place (see the note on VQE_PAIR_SWITCH in vqe_reg.h).
+#define VQE_ENERGY_OWN_CASE(S, D)                                                                   \
+  case S:                                                                                          \
+    if constexpr ((S) < KBA) {                                                                     \
+      _Pragma("unroll") for (int k = 0; k < NP; ++k) {                                            \
+        const int r = ((k >> (S)) << ((S) + 1)) | (k & ((1 << (S)) - 1));                         \
+        const double2 a = L.psi[pbase ^ ((uint32_t)r << 8)];                                      \
+        const double2 bb = own[r];                                                                 \
+        const double v = (a.x * bb.x + a.y * bb.y) * D[k];                                        \
+        if (k & 1) p1s += v; else p0s += v;                                                       \
+      }                                                                                            \
+    }                                                                                              \
+    break;
+
+#define VQE_ENERGY_CONSUME(G, D)                                                                   \
+  {                                                                                                \
+    const GroupMeta m = L.gm[G];                                                                   \
+    const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.x);                        \
+    const int hb = __builtin_amdgcn_readfirstlane(m.hb);                                          \
+    double p0s = 0.0, p1s = 0.0;                                                                   \
+    if (hb >= 8) {                                                                                 \
+      const uint32_t pbase = tid ^ x; /* (tid ^ xlo) | (xhi << 8), r enters by XOR */             \
+      switch (hb - 8) {                                                                            \
+        VQE_ENERGY_OWN_CASE(0, D) VQE_ENERGY_OWN_CASE(1, D) VQE_ENERGY_OWN_CASE(2, D)             \
+        VQE_ENERGY_OWN_CASE(3, D) VQE_ENERGY_OWN_CASE(4, D)                                       \
+        default: break;                                                                            \
+      }                                                                                            \
+    } else {                                                                                       \
+      const uint32_t base = insert0(tid, hb), basex = base ^ x;                                   \
+      _Pragma("unroll") for (int k = 0; k < NP; ++k) {                                            \
+        const uint32_t kc = (uint32_t)k << 9; /* hb < 8: the k bits sit above the inserted 0 */   \
+        if (FULL || tid + (uint32_t)k * kThreads < DIM / 2) {                                     \
+          const double2 bb = L.psi[base ^ kc], a = L.psi[basex ^ kc];                             \
+          const double v = (a.x * bb.x + a.y * bb.y) * D[k];                                      \
+          if (k & 1) p1s += v; else p0s += v;                                                     \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+    acc0 += 2.0 * p0s;                                                                             \
+    acc1 += 2.0 * p1s;                                                                             \
+  }
+
 template <int N>
 __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
   constexpr uint32_t DIM = 1u << N;
   constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;   // pairs per thread
-  constexpr int KB = N > 9 ? N - 9 : 0;                     // log2(NP)
+  constexpr int NA = (DIM + kThreads - 1) / kThreads;       // own amplitudes per thread
+  constexpr int KBA = N > 8 ? N - 8 : 0;                    // log2(NA)
   constexpr int PD = kEnergyPD;
   constexpr bool FULL = DIM / 2 >= kThreads;                // every thread owns NP pairs
   const uint32_t tid = threadIdx.x;
   const double* __restrict__ tables = H.tables;
   double acc0 = 0.0, acc1 = 0.0;
+  // own amplitudes (logical layout p = tid + 256 r) stay in registers for the whole phase
+  double2 own[NA];
+#pragma unroll
+  for (int r = 0; r < NA; ++r) {
+    const uint32_t p = tid + (uint32_t)r * kThreads;
+    own[r] = (DIM >= kThreads || p < DIM) ? L.psi[p] : make_double2(0.0, 0.0);
+  }
   int g0 = 0;
-  if (H.has_diag) {   // diagonal group: full-length table
+  if (H.has_diag) {   // diagonal group: full-length table, no LDS traffic at all
     const double* t = tables + L.gm[0].off_r;
-    constexpr int NA = (DIM + kThreads - 1) / kThreads;
-    double dv[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
       const uint32_t p = tid + (uint32_t)k * kThreads;
-      dv[k] = (DIM >= kThreads || p < DIM) ? t[p] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const uint32_t p = tid + (uint32_t)k * kThreads;
-      if (DIM >= kThreads || p < DIM) {
-        const double2 a = L.psi[p];
-        acc0 += (a.x * a.x + a.y * a.y) * dv[k];
-      }
+      const double dv = (DIM >= kThreads || p < DIM) ? t[p] : 0.0;
+      const double v = (own[k].x * own[k].x + own[k].y * own[k].y) * dv;
+      if (k & 1) acc1 += v; else acc0 += v;
     }
     g0 = 1;
   }
   const int g1 = g0 + H.n_real;        // multiple of PD groups with real tables
   double buf[PD][NP];
-  auto fetch = [&](int g, double (&dst)[NP]) {
-    const double* t = tables + __builtin_amdgcn_readfirstlane(L.gm[g].off_r);
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const uint32_t q = tid + (uint32_t)k * kThreads;
-      dst[k] = (FULL || q < DIM / 2) ? t[q] : 0.0;
-    }
-  };
-  auto consume = [&](int g, const double (&d)[NP]) {
-    const GroupMeta m = L.gm[g];
-    const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.x);
-    const int hb = __builtin_amdgcn_readfirstlane(m.hb);
-    const uint32_t base = insert0(tid, hb), basex = base ^ x;
-    uint32_t kbit[KB > 0 ? KB : 1];
-#pragma unroll
-    for (int i = 0; i < KB; ++i) kbit[i] = 1u << (8 + i + ((8 + i) >= hb ? 1 : 0));
-    double p0s = 0.0, p1s = 0.0;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      uint32_t kc = 0;
-#pragma unroll
-      for (int i = 0; i < KB; ++i) if ((k >> i) & 1) kc ^= kbit[i];
-      if (FULL || tid + (uint32_t)k * kThreads < DIM / 2) {
-        const double2 b = L.psi[base ^ kc], a = L.psi[basex ^ kc];
-        const double v = (a.x * b.x + a.y * b.y) * d[k];
-        if (k & 1) p1s += v; else p0s += v;
-      }
-    }
-    acc0 += 2.0 * p0s;
-    acc1 += 2.0 * p1s;
-  };
   if (g0 < g1) {
 #pragma unroll
-    for (int j = 0; j < PD; ++j) fetch(g0 + j, buf[j]);
+    for (int j = 0; j < PD; ++j) {
+      const double* t = tables + __builtin_amdgcn_readfirstlane(L.gm[g0 + j].off_r);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const uint32_t q = tid + (uint32_t)k * kThreads;
+        buf[j][k] = (FULL || q < DIM / 2) ? t[q] : 0.0;
+      }
+    }
     for (int g = g0; g < g1; g += PD) {
-      const int gn = g + PD < g1 ? g + PD : g;   // last round re-fetches its own (harmless)
+      const int gn = g + PD < g1 ? g + PD : g;   // the last round re-requests its own tables (harmless)
 #pragma unroll
       for (int j = 0; j < PD; ++j) {
-        consume(g + j, buf[j]);
-        fetch(gn + j, buf[j]);
-        // keep the scheduler from hoisting the LDS reads of all PD groups to the top of the
-        // unrolled body (that costs > 256 VGPRs and the second workgroup per CU)
+        VQE_ENERGY_CONSUME(g + j, buf[j])
+        const double* t = tables + __builtin_amdgcn_readfirstlane(L.gm[gn + j].off_r);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const uint32_t q = tid + (uint32_t)k * kThreads;
+          buf[j][k] = (FULL || q < DIM / 2) ? t[q] : 0.0;
+        }
+        // keep the scheduler from hoisting the LDS reads of all PD groups to the top
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -516,6 +541,9 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
 template <int N>
 __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L, const double* theta, int P,
                                                int p_hole = -1) {
+#ifdef VQE_STAMPS
+  const long long t0 = clock64();
+#endif
   if constexpr (N >= kRegMinQubits) {
     run_ops_reg<N>(L, A.init, theta, P, p_hole);
   } else {
@@ -523,7 +551,18 @@ __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L,
     __syncthreads();
     run_ops<N>(L, theta, P, p_hole);
   }
-  return lds_energy<N>(L, A.ham);
+#ifdef VQE_STAMPS
+  const long long t1 = clock64();
+#endif
+  const double e = lds_energy<N>(L, A.ham);
+#ifdef VQE_STAMPS   // diagnostic build only: cycles per phase, summed over workgroups (thread 0)
+  if (threadIdx.x == 0) {
+    atomicAdd(A.dbg + 0, 1ull);
+    atomicAdd(A.dbg + 1, (unsigned long long)(t1 - t0));
+    atomicAdd(A.dbg + 2, (unsigned long long)(clock64() - t1));
+  }
+#endif
+  return e;
 }
 
 // COBYLA with its matrices staged into the state region of LDS while the state is dead
@@ -668,7 +707,14 @@ __global__ void __launch_bounds__(kThreads, (N <= 12 ? 2 : 1)) k_lds_minimize(Ba
       finished_opt = true;
     } else if (phase == 1) {
       flast = e;
-      if (!sc.tell(e)) {
+#ifdef VQE_STAMPS
+      const long long tt0 = clock64();
+#endif
+      const int want = sc.tell(e);
+#ifdef VQE_STAMPS
+      if (threadIdx.x == 0) atomicAdd(A.dbg + 3, (unsigned long long)(clock64() - tt0));
+#endif
+      if (!want) {
         for (int j = threadIdx.x; j < P; j += kThreads) {
           const double v = (j == p_hole) ? theta[j] : cob.x[j - (p_hole >= 0 && j > p_hole)];
           xout[j] = A.env_step ? (double)(float)v : v;

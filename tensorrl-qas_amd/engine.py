@@ -213,6 +213,11 @@ class VQEEngine:
     def batch_copy_energy(self, dst_dev_ptr: int):
         self._chk(self._lib.vqe_batch_copy_energy(self._h, C.c_void_p(int(dst_dev_ptr))))
 
+    def debug_counters(self):
+        out = np.zeros(8, np.uint64)
+        self._chk(self._lib.vqe_debug_counters(self._h, _p(out, c_u64p)))
+        return out
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         self._chk(self._lib.vqe_last_kernel_ms(self._h, C.byref(ms)))
