@@ -55,6 +55,7 @@ struct vqe_handle {
   DevBuf<uint32_t> d_gx, d_term_z;
   DevBuf<double> d_term_cr, d_term_ci, d_tables;
   DevBuf<int32_t> d_tab_r, d_tab_i;
+
   DevBuf<int32_t> d_term_off;
   HamDev ham{};
   NoiseCfg noise{0.0, 0.0, 0ull, 0ull};
@@ -145,14 +146,24 @@ int build_hamiltonian(vqe_t* h) {
     return false;
   };
   auto rank_of = [&](int g) { return h->gx_all[g] == 0 && !group_has_im(g) ? 0 : (group_has_im(g) ? 2 : 1); };
-  if (h->lds_path) std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return rank_of(a) < rank_of(b); });
+  // ... and inside the real section by the top bit of x, so that consecutive groups share
+  // their addressing context (the kernel recomputes it only when that bit changes)
+  auto top_bit = [&](int g) { return h->gx_all[g] ? 31 - __builtin_clz(h->gx_all[g]) : -1; };
+  if (h->lds_path)
+    std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) {
+      return rank_of(a) != rank_of(b) ? rank_of(a) < rank_of(b) : top_bit(a) > top_bit(b);
+    });
   int has_diag = 0, n_real = 0;
   auto add_dummy = [&]() {
-    gx.push_back(1u);
+    // zero table; same top bit as the last real group so it extends that run (x must keep
+    // its top bit: use exactly that bit)
+    uint32_t xd = 1u;
+    for (size_t i = gx.size(); i-- > 0;) if (gx[i]) { xd = 1u << (31 - __builtin_clz(gx[i])); break; }
+    gx.push_back(xd);
     term_off.push_back((int32_t)term_z.size());
     tab_r.push_back((int32_t)tables.size());
     tab_i.push_back(-1);
-    tables.resize(tables.size() + dim / 2 + 1, 0.0);
+    tables.resize(tables.size() + dim / 2, 0.0);
   };
   bool padded = false;
   for (int g : mine) {

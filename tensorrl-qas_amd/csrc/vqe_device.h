@@ -122,7 +122,14 @@ struct DevCtx {
   double* red;   // >= 8 doubles of LDS
   static constexpr int nth = kThreads;
   __device__ void sync() const { __syncthreads(); }
-  __device__ int all_or(int v) const { return __syncthreads_or(v); }
+  __device__ int all_or(int v) const {   // (HIP's __syncthreads_or allocates static LDS)
+    const int any = __ballot(v != 0) != 0ull;
+    int* ired = (int*)(red + 4);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) ired[threadIdx.x >> 6] = any;
+    __syncthreads();
+    return (ired[0] | ired[1] | ired[2] | ired[3]) != 0;
+  }
   template <class F>
   __device__ double sum(int n, F f) const {
     double a = 0.0;
@@ -415,48 +422,46 @@ __device__ __forceinline__ void load_init(const Lds& L, const double2* init) {
 // body is branch free so LDS reads of one group overlap the FMAs of the previous one.
 constexpr int kEnergyPD = 4;
 
-// One pair group with the thread's own amplitudes in registers (x has a bit S+8 >= 8): the
-// "first" member of every pair is an own amplitude own[r] with bit S of r clear, only the
-// partner comes from LDS.  Expanded in place (see the note on VQE_PAIR_SWITCH in vqe_reg.h).
-#define VQE_ENERGY_OWN_CASE(S, D)                                                                   \
-  case S:                                                                                          \
-    if constexpr ((S) < KBA) {                                                                     \
-      _Pragma("unroll") for (int k = 0; k < NP; ++k) {                                            \
-        const int r = ((k >> (S)) << ((S) + 1)) | (k & ((1 << (S)) - 1));                         \
-        const double2 a = L.psi[pbase ^ ((uint32_t)r << 8)];                                      \
-        const double2 bb = own[r];                                                                 \
-        const double v = (a.x * bb.x + a.y * bb.y) * D[k];                                        \
+// All pairs of one group, both members read from LDS in batches of kEnergyBatch pairs (all
+// reads of a batch are in flight together, then the arithmetic).  DEXPR yields D for pair k
+// (register ring or F-table lookup).  Expanded in place (see VQE_PAIR_SWITCH in vqe_reg.h).
+constexpr int kEnergyBatch = 4;
+
+#define VQE_ENERGY_PAIRS(X, HB, DEXPR)                                                             \
+  {                                                                                                \
+    const uint32_t base = insert0(tid, (HB)) << 4, basex = base ^ ((X) << 4);                     \
+    uint32_t kbit[KB > 0 ? KB : 1];                                                                \
+    _Pragma("unroll") for (int i = 0; i < KB; ++i)                                                \
+      kbit[i] = 16u << (8 + i + ((8 + i) >= (HB) ? 1 : 0));                                       \
+    double p0s = 0.0, p1s = 0.0;                                                                   \
+    _Pragma("unroll") for (int k0 = 0; k0 < NP; k0 += kEnergyBatch) {                             \
+      constexpr int NB = NP < kEnergyBatch ? NP : kEnergyBatch;                                   \
+      double2 pa[NB], pb[NB];                                                                      \
+      _Pragma("unroll") for (int kk = 0; kk < NB; ++kk) {                                         \
+        const int k = k0 + kk;                                                                     \
+        uint32_t kc = 0;                                                                           \
+        _Pragma("unroll") for (int i = 0; i < KB; ++i) if ((k >> i) & 1) kc ^= kbit[i];           \
+        const bool live = FULL || tid + (uint32_t)k * kThreads < DIM / 2;                         \
+        pb[kk] = live ? *(const double2*)(psi_b + (base ^ kc)) : make_double2(0.0, 0.0);         \
+        pa[kk] = live ? *(const double2*)(psi_b + (basex ^ kc)) : make_double2(0.0, 0.0);        \
+      }                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+      _Pragma("unroll") for (int kk = 0; kk < NB; ++kk) {                                         \
+        const int k = k0 + kk;                                                                     \
+        const double v = (pa[kk].x * pb[kk].x + pa[kk].y * pb[kk].y) * (DEXPR);                   \
         if (k & 1) p1s += v; else p0s += v;                                                       \
       }                                                                                            \
     }                                                                                              \
-    break;
+    acc0 += 2.0 * p0s;                                                                             \
+    acc1 += 2.0 * p1s;                                                                             \
+  }
 
 #define VQE_ENERGY_CONSUME(G, D)                                                                   \
   {                                                                                                \
     const GroupMeta m = L.gm[G];                                                                   \
     const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.x);                        \
     const int hb = __builtin_amdgcn_readfirstlane(m.hb);                                          \
-    double p0s = 0.0, p1s = 0.0;                                                                   \
-    if (hb >= 8) {                                                                                 \
-      const uint32_t pbase = tid ^ x; /* (tid ^ xlo) | (xhi << 8), r enters by XOR */             \
-      switch (hb - 8) {                                                                            \
-        VQE_ENERGY_OWN_CASE(0, D) VQE_ENERGY_OWN_CASE(1, D) VQE_ENERGY_OWN_CASE(2, D)             \
-        VQE_ENERGY_OWN_CASE(3, D) VQE_ENERGY_OWN_CASE(4, D)                                       \
-        default: break;                                                                            \
-      }                                                                                            \
-    } else {                                                                                       \
-      const uint32_t base = insert0(tid, hb), basex = base ^ x;                                   \
-      _Pragma("unroll") for (int k = 0; k < NP; ++k) {                                            \
-        const uint32_t kc = (uint32_t)k << 9; /* hb < 8: the k bits sit above the inserted 0 */   \
-        if (FULL || tid + (uint32_t)k * kThreads < DIM / 2) {                                     \
-          const double2 bb = L.psi[base ^ kc], a = L.psi[basex ^ kc];                             \
-          const double v = (a.x * bb.x + a.y * bb.y) * D[k];                                      \
-          if (k & 1) p1s += v; else p0s += v;                                                     \
-        }                                                                                          \
-      }                                                                                            \
-    }                                                                                              \
-    acc0 += 2.0 * p0s;                                                                             \
-    acc1 += 2.0 * p1s;                                                                             \
+    VQE_ENERGY_PAIRS(x, hb, D[k])                                                                  \
   }
 
 template <int N>
@@ -464,28 +469,24 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
   constexpr uint32_t DIM = 1u << N;
   constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;   // pairs per thread
   constexpr int NA = (DIM + kThreads - 1) / kThreads;       // own amplitudes per thread
-  constexpr int KBA = N > 8 ? N - 8 : 0;                    // log2(NA)
+  constexpr int KB = N > 9 ? N - 9 : 0;                     // log2(NP)
   constexpr int PD = kEnergyPD;
   constexpr bool FULL = DIM / 2 >= kThreads;                // every thread owns NP pairs
   const uint32_t tid = threadIdx.x;
   const double* __restrict__ tables = H.tables;
+  const unsigned char* psi_b = (const unsigned char*)L.psi;
   double acc0 = 0.0, acc1 = 0.0;
-  // own amplitudes (logical layout p = tid + 256 r) stay in registers for the whole phase
-  double2 own[NA];
-#pragma unroll
-  for (int r = 0; r < NA; ++r) {
-    const uint32_t p = tid + (uint32_t)r * kThreads;
-    own[r] = (DIM >= kThreads || p < DIM) ? L.psi[p] : make_double2(0.0, 0.0);
-  }
   int g0 = 0;
-  if (H.has_diag) {   // diagonal group: full-length table, no LDS traffic at all
+  if (H.has_diag) {   // diagonal group: full-length table
     const double* t = tables + L.gm[0].off_r;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
       const uint32_t p = tid + (uint32_t)k * kThreads;
-      const double dv = (DIM >= kThreads || p < DIM) ? t[p] : 0.0;
-      const double v = (own[k].x * own[k].x + own[k].y * own[k].y) * dv;
-      if (k & 1) acc1 += v; else acc0 += v;
+      if (DIM >= kThreads || p < DIM) {
+        const double2 a = L.psi[p];
+        const double v = (a.x * a.x + a.y * a.y) * t[p];
+        if (k & 1) acc1 += v; else acc0 += v;
+      }
     }
     g0 = 1;
   }
@@ -501,19 +502,85 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
         buf[j][k] = (FULL || q < DIM / 2) ? t[q] : 0.0;
       }
     }
-    for (int g = g0; g < g1; g += PD) {
-      const int gn = g + PD < g1 ? g + PD : g;   // the last round re-requests its own tables (harmless)
+    if constexpr (NP >= 4) {
+      // Software pipeline over half groups: while the arithmetic of one half runs, the LDS
+      // reads of the next half (possibly of the next group) are already in flight.
+      constexpr int HP = NP / 2;
+      double2 aA[HP], bA[HP], aB[HP], bB[HP];
+      // addressing context of the group being loaded.  The X mask of a group is fetched
+      // from LDS one step ahead (xq), so no LDS latency sits in front of the address math;
+      // everything is branch free (conditionals inside this unrolled body make hipcc spill).
+      uint32_t cb, cbx, ckb[KB];
+      uint32_t xq;
+#define VQE_E_CTX(XV)                                                                              \
+      {                                                                                            \
+        const uint32_t x_ = (XV);                                                                  \
+        const int hb_ = 31 - __builtin_clz((int)x_);                                              \
+        cb = insert0(tid, hb_) << 4;                                                               \
+        _Pragma("unroll") for (int i = 0; i < KB; ++i) ckb[i] = 16u << (8 + i + ((8 + i) >= hb_ ? 1 : 0)); \
+        cbx = cb ^ (x_ << 4);                                                                      \
+      }
+#define VQE_E_XFETCH(G) (uint32_t)__builtin_amdgcn_readfirstlane((int)L.gm[(G) < g1 ? (G) : g1 - 1].x)
+#define VQE_E_LOAD(H, PA, PB)                                                                      \
+      _Pragma("unroll") for (int kk = 0; kk < HP; ++kk) {                                         \
+        const int k = (H) * HP + kk;                                                               \
+        uint32_t kc = 0;                                                                           \
+        _Pragma("unroll") for (int i = 0; i < KB; ++i) if ((k >> i) & 1) kc ^= ckb[i];            \
+        PB[kk] = *(const double2*)(psi_b + (cb ^ kc));                                            \
+        PA[kk] = *(const double2*)(psi_b + (cbx ^ kc));                                           \
+      }
+#define VQE_E_COMP(H, PA, PB, D)                                                                   \
+      _Pragma("unroll") for (int kk = 0; kk < HP; ++kk) {                                         \
+        const double v = (PA[kk].x * PB[kk].x + PA[kk].y * PB[kk].y) * D[(H) * HP + kk];          \
+        if (kk & 1) acc1 += v + v; else acc0 += v + v;                                            \
+      }
+      const double* treal = tables + __builtin_amdgcn_readfirstlane(L.gm[g0].off_r);
+      VQE_E_CTX(VQE_E_XFETCH(g0))
+      xq = VQE_E_XFETCH(g0 + 1);
+      VQE_E_LOAD(0, aA, bA)
+      for (int g = g0; g < g1; g += PD) {
 #pragma unroll
-      for (int j = 0; j < PD; ++j) {
-        VQE_ENERGY_CONSUME(g + j, buf[j])
-        const double* t = tables + __builtin_amdgcn_readfirstlane(L.gm[gn + j].off_r);
+        for (int j = 0; j < PD; ++j) {
+          // Refill the ring slot consumed in the PREVIOUS step first, so that these loads
+          // have a whole step to land before anything waits on the vector-memory counter.
+          {
+            const int sl = (j + PD - 1) % PD;
+            int gr = (j == 0) ? (g == g0 ? g0 + PD - 1 : g - 1 + PD) : g + j - 1 + PD;
+            gr = gr < g1 ? gr : g1 - 1;            // slots past the end are never consumed
+            const double* t = treal + (size_t)(gr - g0) * (DIM / 2);   // contiguous, fixed stride
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          const uint32_t q = tid + (uint32_t)k * kThreads;
-          buf[j][k] = (FULL || q < DIM / 2) ? t[q] : 0.0;
+            for (int k = 0; k < NP; ++k) buf[sl][k] = t[tid + (uint32_t)k * kThreads];
+          }
+          VQE_E_LOAD(1, aB, bB)                    // second half of group g+j
+          __builtin_amdgcn_sched_barrier(0);
+          VQE_E_COMP(0, aA, bA, buf[j])
+          __builtin_amdgcn_sched_barrier(0);
+          VQE_E_CTX(xq)                            // next group (g+j+1); its x came in a step ago
+          xq = VQE_E_XFETCH(g + j + 2);
+          VQE_E_LOAD(0, aA, bA)                    // first half of the next group
+          __builtin_amdgcn_sched_barrier(0);
+          VQE_E_COMP(1, aB, bB, buf[j])
+          __builtin_amdgcn_sched_barrier(0);
         }
-        // keep the scheduler from hoisting the LDS reads of all PD groups to the top
-        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef VQE_E_CTX
+#undef VQE_E_XFETCH
+#undef VQE_E_LOAD
+#undef VQE_E_COMP
+    } else {
+      for (int g = g0; g < g1; g += PD) {
+        const int gn = g + PD < g1 ? g + PD : g;
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+          VQE_ENERGY_CONSUME(g + j, buf[j])
+          const double* t = tables + __builtin_amdgcn_readfirstlane(L.gm[gn + j].off_r);
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            const uint32_t q = tid + (uint32_t)k * kThreads;
+            buf[j][k] = (FULL || q < DIM / 2) ? t[q] : 0.0;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
