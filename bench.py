@@ -136,11 +136,29 @@ def heis20_aux(tq, torch, dist, rank, world, dev, steps):
         one()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
+    # the Pauli-term reduction alone (this rank's X-mask groups + the all-reduce), states resident
+    def red():
+        eng.batch_run_reduction()
+        eng.batch_copy_energy(e.data_ptr())
+        if world > 1:
+            dist.all_reduce(e)
+
+    red()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        red()
+    torch.cuda.synchronize()
+    dr = time.perf_counter() - t1
+    t = torch.tensor([dt, dr], dtype=torch.float64, device=f"cuda:{dev}")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return {"workload": "heisenberg_20q_77terms_G32_B8_term_sharded", "evals_per_s": B * steps / float(t.item()),
-            "energy_checksum": float(e.sum().item()), "scaling": "strong"}
+    return {"workload": "heisenberg_20q_77terms_G32_B8_term_sharded", "evals_per_s": B * steps / float(t[0].item()),
+            "reduction_ms_per_batch": float(t[1].item()) / steps * 1e3,
+            "reduction_evals_per_s": B * steps / float(t[1].item()),
+            "x_groups_total": 20, "energy_checksum": float(e.sum().item()), "scaling": "strong"}
 
 
 def main():
@@ -219,6 +237,19 @@ def main():
         dist.all_reduce(stats)
     mean_nfev = float(stats[0].item() / stats[1].item())
 
+    # auxiliary: the same batch warm-started from its own optimum (what an RL episode does:
+    # x0 of a step is the previous step's optimum), one fused launch
+    x_opt, _, _ = eng.batch_fetch()
+    eng.batch_load_flat(batch["gate_off"], batch["kind"], batch["q0"], batch["q1"], batch["pidx"],
+                        batch["par_off"], x_opt)
+    eng.batch_set_new_gate(batch["new_gate"])
+    eng.batch_run_env_step(1.0, 1e-4, args.maxfun)
+    torch.cuda.synchronize()
+    warm_ms = eng.last_kernel_ms()
+    _, _, nfev_w = eng.batch_fetch(want_x=False)
+    warm = {"env_steps_per_s_per_gpu": B / (warm_ms * 1e-3), "mean_nfev": float(nfev_w.mean()),
+            "note": "same circuits, x0 = optimum of the previous step (float32), kernel time only"}
+
     heis = None
     if not args.no_heis20:
         heis = heis20_aux(tq, torch, dist, rank, world, local, max(2, args.steps))
@@ -242,6 +273,13 @@ def main():
                          "achieved_xgrouped": evals_per_launch * bytes_per_eval_grouped / (k_ms * 1e-3) / 1e9,
                          "note": "state is LDS-resident: algorithmic bytes never reach HBM, frac may exceed 1"},
         }
+        out["warm_start"] = warm
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):      # HBM bytes per launch from a separate rocprofv3 --pmc run
+            tr = json.load(open(tfile))
+            if tr.get("workload") == out["config"]["workload"]:
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tr["source"]
         if heis is not None:
             out["heis20"] = heis
         if not args.no_cpu_baseline:

@@ -111,6 +111,9 @@ int vqe_batch_load(vqe_t* h, int batch, const int64_t* gate_off, const int32_t* 
                    const int64_t* par_off, const double* theta0);
 int vqe_batch_run_energy(vqe_t* h);
 int vqe_batch_run_minimize(vqe_t* h, double rhobeg, double rhoend, int maxfun);
+/* streaming path (n >= 14): redo only the Pauli-term reduction <psi|H_shard|psi> on the
+ * states left by the previous vqe_batch_run_energy (for timing the sharded reduction) */
+int vqe_batch_run_reduction(vqe_t* h);
 /* One CircuitEnv.step() worth of arithmetic per circuit, in ONE launch
  * (environment_qulacs_TN_notin_agent.py:283-291): new_gate[b] is the index, inside circuit
  * b, of the gate the RL action just added (-1: none).  COBYLA runs on the circuit WITHOUT

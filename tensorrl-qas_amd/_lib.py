@@ -34,6 +34,7 @@ SIGNATURES = {
     "vqe_minimize_cobyla": (C.c_int, [vp, c_f64p, C.c_double, C.c_double, C.c_int, c_f64p, c_f64p, c_i32p]),
     "vqe_batch_load": (C.c_int, [vp, C.c_int, c_i64p, c_i32p, c_i32p, c_i32p, c_i32p, c_i64p, c_f64p]),
     "vqe_batch_run_energy": (C.c_int, [vp]),
+    "vqe_batch_run_reduction": (C.c_int, [vp]),
     "vqe_batch_run_minimize": (C.c_int, [vp, C.c_double, C.c_double, C.c_int]),
     "vqe_batch_set_new_gate": (C.c_int, [vp, c_i32p]),
     "vqe_batch_run_env_step": (C.c_int, [vp, C.c_double, C.c_double, C.c_int]),

@@ -376,6 +376,9 @@ int stream_run(vqe_t* h, int which, BatchArgs& A) {
   int rc = 0;
   if (which == 0) {
     rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base, true, h->err);
+  } else if (which == 4) {   // Pauli-term reduction only, on the states of the previous run
+    if (h->sw.states_cap < ((size_t)h->batch << h->n)) return fail(h, VQE_ESTATE, "no states: run the energy first");
+    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base, true, h->err, false);
   } else if (which == 2) {
     rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base, false, h->err);
     if (!rc) {
@@ -437,11 +440,13 @@ int run(vqe_t* h, int which, double rhobeg, double rhoend, int maxfun) {
   if (which == 1 && h->shard_world > 1)
     return fail(h, VQE_ESTATE, "term-sharded handles hold partial energies: drive COBYLA with "
                                "vqe_cobyla_ask/tell and sum the partial energies of all ranks");
+  if (which == 4 && h->lds_path)
+    return fail(h, VQE_ESTATE, "the reduction-only launch exists on the streaming path (n >= 14) only");
   if (h->lds_path) rc = dispatch_lds(h, which, A);
   else rc = stream_run(h, which, A);
   if (rc) return rc;
   // every evaluation of a stochastic run consumes fresh trajectory numbers
-  h->noise.eval_base += (which == 1 ? (uint64_t)maxfun + 1 : 1);
+  if (which != 4) h->noise.eval_base += (which == 1 ? (uint64_t)maxfun + 1 : 1);
   return VQE_OK;
 }
 
@@ -661,6 +666,12 @@ int vqe_batch_run_energy(vqe_t* h) {
   int rc = ready(h);
   if (rc) return rc;
   return run(h, 0, 0, 0, 0);
+}
+
+int vqe_batch_run_reduction(vqe_t* h) {
+  int rc = ready(h);
+  if (rc) return rc;
+  return run(h, 4, 0, 0, 0);
 }
 
 int vqe_batch_run_minimize(vqe_t* h, double rhobeg, double rhoend, int maxfun) {

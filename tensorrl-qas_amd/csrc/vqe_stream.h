@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(kThreads) k_s_state_out(BatchArgs A, const dou
 
 // circuit + (partial) energy of every resident stream, results in A.fout (device)
 inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipStream_t st,
-                           uint64_t eval_id, bool want_energy, std::string& err) {
+                           uint64_t eval_id, bool want_energy, std::string& err, bool want_circuit = true) {
   const size_t dim = (size_t)1 << A.n;
   const int B = A.batch;
   SW_TRY(sw_reserve(sw.states, sw.states_cap, (size_t)B * dim));
@@ -266,12 +266,14 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
   const int eblk = (int)(dim / (kThreads * kEnergyApt));
   SW_TRY(sw_reserve(sw.partial, sw.partial_cap, (size_t)B * eblk));
 
-  hipLaunchKernelGGL(k_s_compile, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.masks, sw.meta, eval_id);
-  hipLaunchKernelGGL(k_s_sincos, dim3((A.max_params + 63) / 64, B), dim3(64), 0, st, A, sw.cs);
-  hipLaunchKernelGGL(k_s_init, dim3((unsigned)(dim / kThreads), B), dim3(kThreads), 0, st, A, sw.states);
-  for (int o = 0; o < A.max_ops; ++o)
-    hipLaunchKernelGGL(k_s_op, dim3((unsigned)(dim / 2 / kThreads), B), dim3(kThreads), 0, st, A, sw.states,
-                       sw.ops, sw.meta, sw.cs, o);
+  if (want_circuit) {
+    hipLaunchKernelGGL(k_s_compile, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.masks, sw.meta, eval_id);
+    hipLaunchKernelGGL(k_s_sincos, dim3((A.max_params + 63) / 64, B), dim3(64), 0, st, A, sw.cs);
+    hipLaunchKernelGGL(k_s_init, dim3((unsigned)(dim / kThreads), B), dim3(kThreads), 0, st, A, sw.states);
+    for (int o = 0; o < A.max_ops; ++o)
+      hipLaunchKernelGGL(k_s_op, dim3((unsigned)(dim / 2 / kThreads), B), dim3(kThreads), 0, st, A, sw.states,
+                         sw.ops, sw.meta, sw.cs, o);
+  }
   if (want_energy) {
     const int m = std::max(nt, ng);
     hipLaunchKernelGGL(k_s_terms, dim3((m + 63) / 64, B), dim3(64), 0, st, A, sw.masks, sw.meta, n_terms,

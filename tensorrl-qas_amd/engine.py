@@ -177,6 +177,9 @@ class VQEEngine:
     def batch_run_energy(self):
         self._chk(self._lib.vqe_batch_run_energy(self._h))
 
+    def batch_run_reduction(self):
+        self._chk(self._lib.vqe_batch_run_reduction(self._h))
+
     def batch_run_minimize(self, rhobeg=1.0, rhoend=1e-4, maxfun=1000):
         self._chk(self._lib.vqe_batch_run_minimize(self._h, rhobeg, rhoend, int(maxfun)))
 
