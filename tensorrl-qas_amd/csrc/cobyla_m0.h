@@ -145,6 +145,23 @@ struct CobylaM0 {
   // m = 0 trust-region step: dx = rho * a/|a| accumulated as the general routine does.
   // Uses w[0..n) for the running direction and w[n..2n) is not needed.  Sets ifull.
   CBY_HD void trstlp_m0() {
+    if (Ctx::nth > 1) {
+      // Parallel contexts: the closed form dx = rho * a / |a| directly (one reduction, no
+      // serial chain of n square roots and 2n divisions).  Same step as the Givens form
+      // below up to rounding.
+      const double nrm2 = ctx.sum(n, [&](int i) { return a[i] * a[i]; });
+      if (nrm2 == 0.0) {
+        for (int i = ctx.tid; i < n; i += ctx.nth) dx[i] = 0.0;
+        ifull = 0;
+        ctx.sync();
+        return;
+      }
+      const double scale = rho / sqrt(nrm2);
+      for (int i = ctx.tid; i < n; i += ctx.nth) dx[i] = scale * a[i];
+      ifull = 1;
+      ctx.sync();
+      return;
+    }
     // Givens accumulation from k = n-1 down to 0 on Z = I (all threads, redundantly, for
     // the scalar chain; the direction vector is built in parallel afterwards).
     double tot = 0.0;

@@ -196,7 +196,8 @@ int build_hamiltonian(vqe_t* h) {
         for (size_t q = 0; q < len; ++q) {
           const uint32_t p = x == 0 ? (uint32_t)q
                                     : (uint32_t)(((q >> hb) << (hb + 1)) | (q & (((size_t)1 << hb) - 1)));
-          const double sgn = (__builtin_popcount(p & z) & 1) ? -1.0 : 1.0;
+          // pair tables carry the factor 2 of the p <-> p^x symmetry
+          const double sgn = ((__builtin_popcount(p & z) & 1) ? -1.0 : 1.0) * (x == 0 ? 1.0 : 2.0);
           tr[q] += sgn * h->hcr[k];
           if (ti) ti[q] += sgn * h->hci[k];
         }

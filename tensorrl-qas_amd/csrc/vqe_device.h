@@ -452,8 +452,8 @@ constexpr int kEnergyBatch = 4;
         if (k & 1) p1s += v; else p0s += v;                                                       \
       }                                                                                            \
     }                                                                                              \
-    acc0 += 2.0 * p0s;                                                                             \
-    acc1 += 2.0 * p1s;                                                                             \
+    acc0 += p0s;   /* pair tables hold 2*D */                                                      \
+    acc1 += p1s;                                                                                   \
   }
 
 #define VQE_ENERGY_CONSUME(G, D)                                                                   \
@@ -532,7 +532,7 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
 #define VQE_E_COMP(H, PA, PB, D)                                                                   \
       _Pragma("unroll") for (int kk = 0; kk < HP; ++kk) {                                         \
         const double v = (PA[kk].x * PB[kk].x + PA[kk].y * PB[kk].y) * D[(H) * HP + kk];          \
-        if (kk & 1) acc1 += v + v; else acc0 += v + v;                                            \
+        if (kk & 1) acc1 += v; else acc0 += v;       /* pair tables hold 2*D */                   \
       }
       const double* treal = tables + __builtin_amdgcn_readfirstlane(L.gm[g0].off_r);
       VQE_E_CTX(VQE_E_XFETCH(g0))
@@ -599,7 +599,7 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
         part += (a.x * b.x + a.y * b.y) * tr[q] - (a.x * b.y - a.y * b.x) * ti[q];
       }
     }
-    acc0 += 2.0 * part;
+    acc0 += part;   // pair tables hold 2*D
   }
   return block_sum(acc0 + acc1, L.red);
 }

@@ -216,8 +216,15 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
   uint32_t base = deposit8(tid, L.lay[0].pos);
   __syncthreads();   // cs[] visible
   const int nops = L.meta[4];
+  // descriptor and (cos, sin) of op o+1 are fetched while op o runs (the sched array has a
+  // spare slot; an index outside [0, P) reads entry 0: always valid LDS addresses)
+  Op nxt = L.sched[0];
+  double2 ncs = L.cs[(unsigned)nxt.pidx < (unsigned)P ? nxt.pidx : 0];
   for (int o = 0; o < nops; ++o) {
-    const Op op = L.sched[o];
+    const Op op = nxt;
+    const double2 cs = ncs;
+    nxt = L.sched[o + 1];
+    ncs = L.cs[(unsigned)nxt.pidx < (unsigned)P ? nxt.pidx : 0];
     const int kind = op.kind & 0xff;
     if (kind == OP_RELAYOUT) {
       __syncthreads();                                   // earlier reads of psi are done
@@ -236,13 +243,10 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
     const uint32_t flip = (uint32_t)(parity32(op.zm & base) ^ inv);
     const uint32_t w = sign_word<R>(op.xm >> 8) ^ (0u - flip);
     if (kind == OP_RX) {
-      const double2 cs = L.cs[op.pidx];
       VQE_PAIR_SWITCH((int)(op.xm & 0xff), rx_pairs, amp, cs.x, cs.y)
     } else if (kind == OP_RY) {
-      const double2 cs = L.cs[op.pidx];
       VQE_PAIR_SWITCH((int)(op.xm & 0xff), ry_pairs, amp, cs.x, cs.y, w)
     } else if (kind == OP_RZ) {
-      const double2 cs = L.cs[op.pidx];
 #pragma unroll
       for (int r = 0; r < NA; ++r) {
         const double s = flip_if(cs.y, w, r);
