@@ -327,3 +327,64 @@ def test_noise_trajectories_match_oracle(tq):
     # state incl. the global phase of Y errors
     dr = co.noise_draws(seed, 0, 13, kind, p1, p2)
     assert np.abs(eng.get_state(th) - vo.run_circuit(psi0, kind, q0, q1, pidx, th, dr)).max() < A_TOL
+
+
+@pytest.mark.parametrize("n,G,seed", [(9, 40, 0), (10, 60, 1), (11, 90, 2), (13, 70, 3)])
+def test_register_path_sizes(tq, n, G, seed):
+    """n = 10..13 run with the amplitudes in registers (coset layouts), n = 9 is the largest
+    size of the plain LDS-state variant: states, energies (incl. imaginary tables) and a short
+    device COBYLA run at every size."""
+    rng = np.random.default_rng(400 + seed)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 40, rng, real=False)
+    kind, q0, q1, pidx, th = random_gates(n, G, rng, p_cnot=0.45)
+    eng = _engine(tq, n, psi0, ham)
+    eng.set_circuit(tq.Circuit(kind, q0, q1, pidx, th.size))
+    psi = vo.run_circuit(psi0, kind, q0, q1, pidx, th)
+    assert np.abs(eng.get_state(th) - psi).max() < A_TOL
+    e0 = vo.energy_pauli(psi, *ham)
+    assert abs(eng.energy(th) - e0) < E_TOL
+    x, f, nfev = eng.minimize_cobyla(th, 1.0, 1e-4, 60)
+    assert nfev == 60 or nfev < 60
+    assert abs(vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, x), *ham) - f) < E_TOL
+    assert f <= e0 + 1e-12
+
+
+def test_edge_cases(tq):
+    """Empty Hamiltonian, empty circuit, a circuit of CNOTs only, rotations on one qubit only
+    (a single layout), and the largest gate count the LDS path accepts at n = 12."""
+    n = 12
+    rng = np.random.default_rng(77)
+    psi0 = random_state(n, rng)
+    eng = tq.VQEEngine(n)
+    eng.set_init_state(psi0)
+    eng.set_hamiltonian(np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0))
+    eng.set_circuit(tq.Circuit.empty())
+    assert eng.energy(np.zeros(0)) == 0.0
+    ham = random_hamiltonian(n, 25, rng)
+    eng.set_hamiltonian(*ham)
+    assert abs(eng.energy(np.zeros(0)) - vo.energy_pauli(psi0, *ham)) < E_TOL
+    # CNOTs only: pure relabelling, no amplitude ever moves before the final gather
+    kind = np.zeros(40, np.int32)
+    c = rng.integers(0, n, 40)
+    t = (c + 1 + rng.integers(0, n - 1, 40)) % n
+    circ = tq.Circuit(kind, c, t, np.full(40, -1), 0)
+    eng.set_circuit(circ)
+    psi = vo.run_circuit(psi0, kind, c, t, np.full(40, -1), np.zeros(0))
+    assert np.abs(eng.get_state(np.zeros(0)) - psi).max() < A_TOL
+    assert abs(eng.energy(np.zeros(0)) - vo.energy_pauli(psi, *ham)) < E_TOL
+    # 300 rotations on the same qubit
+    G = 300
+    kind = rng.integers(1, 4, G).astype(np.int32)
+    q = np.full(G, 5, np.int32)
+    pid = np.arange(G, dtype=np.int32)
+    th = rng.uniform(-np.pi, np.pi, G)
+    eng.set_circuit(tq.Circuit(kind, q, np.full(G, -1), pid, G))
+    psi = vo.run_circuit(psi0, kind, q, np.full(G, -1), pid, th)
+    assert np.abs(eng.get_state(th) - psi).max() < 5e-12
+    # too many gates for the LDS budget: a clean error, not a crash
+    G = 4000
+    kind = rng.integers(1, 4, G).astype(np.int32)
+    eng.set_circuit(tq.Circuit(kind, rng.integers(0, n, G), np.full(G, -1), np.arange(G), G))
+    with pytest.raises(tq.VQEError):
+        eng.energy(np.zeros(G))
