@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-heis20", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' "
+                    "only to rehearse the multi-rank code path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     import torch
@@ -185,11 +187,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the VQE engine has no CPU fallback")
+    if args.backend != "nccl":                   # rehearsal: ranks share the visible GPUs
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     torch.cuda.set_stream(torch.cuda.Stream())   # one explicit stream for the engine, copies and RCCL
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     n, B, G = N_QUBITS, args.envs, args.gates
     ham = tq.hamiltonian.synthetic_lih12()

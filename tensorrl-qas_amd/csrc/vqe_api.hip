@@ -263,7 +263,7 @@ int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   h->last_wg_per_cu = std::max(1, std::min(8, (int)(h->lds_per_cu / lds)));
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-  const dim3 grid(which == 2 ? 1 : A.batch), block(kThreads);
+  const dim3 grid(which == 2 ? 1 : A.batch), block(Geo<N>::NT);
   if (which == 0) hipLaunchKernelGGL(k_lds_energy<N>, grid, block, lds, h->stream, A);
   else if (which == 1) hipLaunchKernelGGL(k_lds_minimize<N>, grid, block, lds, h->stream, A);
   else hipLaunchKernelGGL(k_lds_state<N>, grid, block, lds, h->stream, A);

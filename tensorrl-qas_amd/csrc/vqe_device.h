@@ -24,7 +24,23 @@
 
 namespace vqe {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;   // default workgroup size (n <= 11 and the streaming path)
+
+// Workgroup geometry of the LDS-resident kernels.
+//  * n <= 11: 256 threads, registers capped for 4 waves per SIMD (4 workgroups per CU fit the
+//    LDS): measured at n = 11 +31 % over 2 waves per SIMD although the cap costs spills - the
+//    vector-memory, LDS and VALU pipes of the energy step overlap better across more waves;
+//  * n = 12: 256 threads x 16 amplitudes, 2 workgroups per CU (LDS bound), 256 VGPRs.  The
+//    512-thread variant (8 amplitudes per thread, 4 waves per SIMD in 128 VGPRs) was measured
+//    15 % slower: 124 spilled registers and one more re-layout per ~3 rotations;
+//  * n = 13: 512 threads x 16 amplitudes, one workgroup per CU.
+template <int N>
+struct Geo {
+  static constexpr int NT = N >= 13 ? 512 : 256;   // threads per workgroup
+  static constexpr int LT = N >= 13 ? 9 : 8;       // log2(NT)
+  static constexpr int NW = NT / 64;               // waves per workgroup
+  static constexpr int WPS = N <= 11 ? 4 : 2;      // waves per SIMD asked of the register allocator
+};
 
 enum : int { G_CNOT = 0, G_RX = 1, G_RY = 2, G_RZ = 3, G_DEPOL1 = 4, G_DEPOL2 = 5 };
 enum : int { OP_RX = 1, OP_RY = 2, OP_RZ = 3, OP_PZ = 4 };
@@ -105,42 +121,51 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// Sum over the 256 threads of the block; every thread receives the identical value.
-__device__ __forceinline__ double block_sum(double v, double* red /* >= 4 doubles LDS */) {
+// Sum over the NW*64 threads of the block; every thread receives the identical value.
+template <int NW = 4>
+__device__ __forceinline__ double block_sum(double v, double* red /* >= NW doubles LDS */) {
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; w += 2) t += red[w] + red[w + 1];
+  return t;
 }
 
 // Workgroup execution context of cobyla_m0.h: strided loops, block-wide reductions.  Sums
 // are taken in a different order than on the host (same algorithm, results differ in the
 // last bits).
+template <int NT>
 struct DevCtx {
   int tid;
-  double* red;   // >= 8 doubles of LDS
-  static constexpr int nth = kThreads;
+  double* red;   // >= 12 doubles of LDS (NW sums + NW indices)
+  static constexpr int nth = NT;
+  static constexpr int NW = NT / 64;
   __device__ void sync() const { __syncthreads(); }
   __device__ int all_or(int v) const {   // (HIP's __syncthreads_or allocates static LDS)
     const int any = __ballot(v != 0) != 0ull;
-    int* ired = (int*)(red + 4);
+    int* ired = (int*)(red + NW);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) ired[threadIdx.x >> 6] = any;
     __syncthreads();
-    return (ired[0] | ired[1] | ired[2] | ired[3]) != 0;
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) r |= ired[w];
+    return r != 0;
   }
   template <class F>
   __device__ double sum(int n, F f) const {
     double a = 0.0;
-    for (int i = tid; i < n; i += kThreads) a += f(i);
-    return block_sum(a, red);
+    for (int i = tid; i < n; i += NT) a += f(i);
+    return block_sum<NW>(a, red);
   }
   template <class F>
   __device__ int arg_first(int n, F f, double thresh, bool want_max, double* val) const {
     double best = thresh;
     int idx = 0x7fffffff;
-    for (int i = tid; i < n; i += kThreads) {
+    for (int i = tid; i < n; i += NT) {
       const double v = f(i);
       if (want_max ? (v > best) : (v < best)) { best = v; idx = i; }
     }
@@ -154,13 +179,13 @@ struct DevCtx {
       const int oi = __shfl_xor(idx, o, 64);
       merge(ob, oi);
     }
-    int* ired = (int*)(red + 4);
+    int* ired = (int*)(red + NW);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = best; ired[threadIdx.x >> 6] = idx; }
     __syncthreads();
     best = red[0]; idx = ired[0];
 #pragma unroll
-    for (int wv = 1; wv < 4; ++wv) merge(red[wv], ired[wv]);
+    for (int wv = 1; wv < NW; ++wv) merge(red[wv], ired[wv]);
     *val = best;
     return idx == 0x7fffffff ? -1 : idx;
   }
@@ -177,7 +202,7 @@ struct Lds {
   LayoutRec* lay;   // [max_ops+2] layouts (register path)
   double2* cs;      // [max_params] (cos, sin)(theta/2)
   GroupMeta* gm;    // [n_groups]
-  double* red;      // [8]
+  double* red;      // [16]
   uint32_t* xm;     // [32] columns of A^-1
   uint32_t* zm;     // [32] rows of A
   int32_t* meta;    // [8]: n_ops, offset c, phase power, permuted flag, n_sched, n_layouts
@@ -190,7 +215,7 @@ __host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params, 
   size_t b = (size_t)16 << n;
   b += n >= 10 ? (size_t)16 * (2 * max_ops + 2) + (size_t)32 * (max_ops + 2) : (size_t)16 * max_ops;
   b += (size_t)16 * max_params + (size_t)16 * ng;
-  return b + 64 + 128 + 128 + 32 + 64;
+  return b + 128 + 128 + 128 + 32 + 64;
 }
 
 __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, int max_params, int n_groups) {
@@ -207,7 +232,7 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, in
   }
   l.cs = (double2*)base; base += (size_t)16 * max_params;
   l.gm = (GroupMeta*)base; base += (size_t)16 * ng;
-  l.red = (double*)base; base += 64;
+  l.red = (double*)base; base += 128;
   l.xm = (uint32_t*)base; base += 128;
   l.zm = (uint32_t*)base; base += 128;
   l.meta = (int32_t*)base; base += 32;
@@ -217,7 +242,7 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, in
 
 // Once per kernel: X-mask group descriptors into LDS (no dependent global loads later).
 __device__ __forceinline__ void stage_groups(const HamDev& H, const Lds& L) {
-  for (int g = threadIdx.x; g < H.n_groups; g += kThreads) {
+  for (int g = threadIdx.x; g < H.n_groups; g += (int)blockDim.x) {
     const uint32_t x = H.gx[g];
     L.gm[g] = GroupMeta{x, x ? 31 - __clz((int)x) : 0, H.tab_r[g], H.tab_i[g]};
   }
@@ -236,7 +261,7 @@ __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t 
   if (staged) {
     const int4* s4 = (const int4*)gsrc;
     int4* d4 = (int4*)gl;
-    for (int i = threadIdx.x; i < G; i += kThreads) d4[i] = s4[i];
+    for (int i = threadIdx.x; i < G; i += (int)blockDim.x) d4[i] = s4[i];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -315,6 +340,7 @@ __device__ __forceinline__ void compile_all(const BatchArgs& A, int b, uint64_t 
 // of the circuit without the rotation whose parameter index is p_hole.
 template <int N>
 __device__ __forceinline__ void run_ops(const Lds& L, const double* theta, int P, int p_hole = -1) {
+  constexpr int kThreads = Geo<N>::NT;   // shadows the default: this kernel family's block size
   constexpr uint32_t DIM = 1u << N;
   constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;   // pairs per thread
   constexpr int NA = (DIM + kThreads - 1) / kThreads;       // amplitudes per thread
@@ -406,6 +432,7 @@ __device__ __forceinline__ void run_ops(const Lds& L, const double* theta, int P
 
 template <int N>
 __device__ __forceinline__ void load_init(const Lds& L, const double2* init) {
+  constexpr int kThreads = Geo<N>::NT;   // shadows the default: this kernel family's block size
   constexpr uint32_t DIM = 1u << N;
   constexpr int NA = (DIM + kThreads - 1) / kThreads;
 #pragma unroll
@@ -432,7 +459,7 @@ constexpr int kEnergyBatch = 4;
     const uint32_t base = insert0(tid, (HB)) << 4, basex = base ^ ((X) << 4);                     \
     uint32_t kbit[KB > 0 ? KB : 1];                                                                \
     _Pragma("unroll") for (int i = 0; i < KB; ++i)                                                \
-      kbit[i] = 16u << (8 + i + ((8 + i) >= (HB) ? 1 : 0));                                       \
+      kbit[i] = 16u << (LT + i + ((LT + i) >= (HB) ? 1 : 0));                                     \
     double p0s = 0.0, p1s = 0.0;                                                                   \
     _Pragma("unroll") for (int k0 = 0; k0 < NP; k0 += kEnergyBatch) {                             \
       constexpr int NB = NP < kEnergyBatch ? NP : kEnergyBatch;                                   \
@@ -466,10 +493,12 @@ constexpr int kEnergyBatch = 4;
 
 template <int N>
 __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
+  constexpr int kThreads = Geo<N>::NT;   // shadows the default: this kernel family's block size
   constexpr uint32_t DIM = 1u << N;
   constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;   // pairs per thread
   constexpr int NA = (DIM + kThreads - 1) / kThreads;       // own amplitudes per thread
-  constexpr int KB = N > 9 ? N - 9 : 0;                     // log2(NP)
+  constexpr int LT = Geo<N>::LT;
+  constexpr int KB = N > LT + 1 ? N - LT - 1 : 0;           // log2(NP)
   constexpr int PD = kEnergyPD;
   constexpr bool FULL = DIM / 2 >= kThreads;                // every thread owns NP pairs
   const uint32_t tid = threadIdx.x;
@@ -517,7 +546,7 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
         const uint32_t x_ = (XV);                                                                  \
         const int hb_ = 31 - __builtin_clz((int)x_);                                              \
         cb = insert0(tid, hb_) << 4;                                                               \
-        _Pragma("unroll") for (int i = 0; i < KB; ++i) ckb[i] = 16u << (8 + i + ((8 + i) >= hb_ ? 1 : 0)); \
+        _Pragma("unroll") for (int i = 0; i < KB; ++i) ckb[i] = 16u << (LT + i + ((LT + i) >= hb_ ? 1 : 0)); \
         cbx = cb ^ (x_ << 4);                                                                      \
       }
 #define VQE_E_XFETCH(G) (uint32_t)__builtin_amdgcn_readfirstlane((int)L.gm[(G) < g1 ? (G) : g1 - 1].x)
@@ -601,7 +630,7 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
     }
     acc0 += part;   // pair tables hold 2*D
   }
-  return block_sum(acc0 + acc1, L.red);
+  return block_sum<Geo<N>::NW>(acc0 + acc1, L.red);
 }
 
 // One evaluation with the ops already compiled: circuit, then <psi|H|psi>.
@@ -636,7 +665,8 @@ __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L,
 // (between two evaluations); falls back to the global scratch when they do not fit.
 template <int N>
 struct StagedCobyla {
-  cby::CobylaM0<DevCtx> cob;
+  static constexpr int kThreads = Geo<N>::NT;
+  cby::CobylaM0<DevCtx<Geo<N>::NT>> cob;
   double* gmem;
   double* lmem;
   int words;
@@ -683,7 +713,8 @@ struct StagedCobyla {
 
 // ---- kernels -----------------------------------------------------------------------------
 template <int N>
-__global__ void __launch_bounds__(kThreads) k_lds_energy(BatchArgs A) {
+__global__ void __launch_bounds__(Geo<N>::NT) k_lds_energy(BatchArgs A) {
+  constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
   const int b = blockIdx.x;
@@ -695,7 +726,8 @@ __global__ void __launch_bounds__(kThreads) k_lds_energy(BatchArgs A) {
 }
 
 template <int N>
-__global__ void __launch_bounds__(kThreads) k_lds_state(BatchArgs A) {
+__global__ void __launch_bounds__(Geo<N>::NT) k_lds_state(BatchArgs A) {
+  constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
   compile_all<N>(A, 0, A.noise.eval_base, L);
@@ -725,7 +757,8 @@ __global__ void __launch_bounds__(kThreads) k_lds_state(BatchArgs A) {
 // variable), and with env_step = 1 the optimum is rounded to float32 (the state tensor's
 // dtype, :480) and the energy of the FULL circuit is reported (:291).
 template <int N>
-__global__ void __launch_bounds__(kThreads, (N <= 12 ? 2 : 1)) k_lds_minimize(BatchArgs A) {
+__global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchArgs A) {
+  constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
   const int b = blockIdx.x;
@@ -742,7 +775,7 @@ __global__ void __launch_bounds__(kThreads, (N <= 12 ? 2 : 1)) k_lds_minimize(Ba
   const int Popt = P - (p_hole >= 0);
   stage_groups(A.ham, L);
   StagedCobyla<N> sc;
-  cby::CobylaM0<DevCtx>& cob = sc.cob;
+  cby::CobylaM0<DevCtx<Geo<N>::NT>>& cob = sc.cob;
   // phases: 0 = single evaluation (empty x0: scipy returns after one call), 1 = COBYLA loop,
   // 2 = post-action evaluation of env_step.  ONE evaluation call site keeps everything inlined.
   int phase = 0, nfev = 1;

@@ -24,8 +24,9 @@ enum : int { OP_RELAYOUT = 5 };
 
 struct LayoutRec {  // 32 bytes
   uint32_t e[5];     // register directions (reduced echelon form)
-  uint32_t pos;      // 8 x 4 bits: non-pivot bit positions, ascending
-  uint32_t pad[2];
+  uint32_t pos;      // 8 x 4 bits: non-pivot bit positions 0..7, ascending
+  uint32_t pos8;     // the ninth position (512-thread workgroups)
+  uint32_t pad;
 };
 
 // ---- scheduler (thread 0) ---------------------------------------------------------------------
@@ -58,17 +59,21 @@ __device__ __forceinline__ void emit_layout(const Basis& B, LayoutRec* out) {
   uint32_t pivmask = 0;
   for (int i = 0; i < 5; ++i) out->e[i] = i < B.k ? B.e[i] : 0u;
   for (int i = 0; i < B.k; ++i) pivmask |= 1u << B.piv[i];
-  uint32_t pos = 0;
+  uint32_t pos = 0, pos8 = 0;
   int cnt = 0;
   for (int b = 0; b < N; ++b)
-    if (!((pivmask >> b) & 1u)) { pos |= (uint32_t)b << (4 * cnt); ++cnt; }
+    if (!((pivmask >> b) & 1u)) {
+      if (cnt < 8) pos |= (uint32_t)b << (4 * cnt); else pos8 = (uint32_t)b;
+      ++cnt;
+    }
   out->pos = pos;
+  out->pos8 = pos8;
 }
 
 // raw ops (L.ops, n = meta[0]) -> scheduled ops (L.sched, n = meta[4]) + layouts (L.lay)
 template <int N>
 __device__ __forceinline__ void schedule_ops(const Lds& L) {
-  constexpr int R = N - 8;
+  constexpr int R = N - Geo<N>::LT;
   const int nraw = L.meta[0];
   int ns = 0, nl = 0;
   Basis B;
@@ -105,10 +110,12 @@ __device__ __forceinline__ void schedule_ops(const Lds& L) {
 }
 
 // ---- per-thread helpers -----------------------------------------------------------------------
-__device__ __forceinline__ uint32_t deposit8(uint32_t tid, uint32_t pos) {
+template <int LT>
+__device__ __forceinline__ uint32_t deposit(uint32_t tid, uint32_t pos, uint32_t pos8) {
   uint32_t b = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) b |= ((tid >> j) & 1u) << ((pos >> (4 * j)) & 15u);
+  if (LT > 8) b |= ((tid >> 8) & 1u) << pos8;
   return b;
 }
 
@@ -194,7 +201,9 @@ __device__ __forceinline__ void ry_pairs(double2 (&amp)[NA], double c, double s,
 template <int N>
 __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restrict__ init, const double* theta, int P,
                                    int p_hole = -1) {
-  constexpr int R = N - 8;
+  constexpr int kThreads = Geo<N>::NT;
+  constexpr int LT = Geo<N>::LT;
+  constexpr int R = N - LT;
   constexpr int NA = 1 << R;
   const int tid = threadIdx.x;
   for (int j = tid; j < P; j += kThreads) {
@@ -209,11 +218,11 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
     const LayoutRec lr = L.lay[0];
 #pragma unroll
     for (int i = 0; i < 5; ++i) e[i] = lr.e[i];
-    const uint32_t base0 = deposit8(tid, lr.pos);
+    const uint32_t base0 = deposit<LT>(tid, lr.pos, lr.pos8);
 #pragma unroll
     for (int r = 0; r < NA; ++r) amp[r] = init[base0 ^ combo<R>(e, r)];
   }
-  uint32_t base = deposit8(tid, L.lay[0].pos);
+  uint32_t base = deposit<LT>(tid, L.lay[0].pos, L.lay[0].pos8);
   __syncthreads();   // cs[] visible
   const int nops = L.meta[4];
   // descriptor and (cos, sin) of op o+1 are fetched while op o runs (the sched array has a
@@ -233,7 +242,7 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
       const LayoutRec lr = L.lay[op.xm];
 #pragma unroll
       for (int i = 0; i < 5; ++i) e[i] = lr.e[i];
-      base = deposit8(tid, lr.pos);
+      base = deposit<LT>(tid, lr.pos, lr.pos8);
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < NA; ++r) amp[r] = L.psi[base ^ combo<R>(e, r)];
