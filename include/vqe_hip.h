@@ -74,6 +74,12 @@ int vqe_set_hamiltonian_pauli(vqe_t* h, int n_terms, const uint64_t* xmask,
 /* Evaluate only the X-mask groups owned by `rank` of `world` (Pauli-term sharding; the
  * caller sums the partial energies of all ranks, e.g. one RCCL all-reduce). */
 int vqe_set_term_shard(vqe_t* h, int rank, int world);
+/* Streaming path (n >= 14) only: sweep slice `rank` of `world` equal slices of the amplitude
+ * index range for ALL terms (the other partition of the double sum over terms and basis
+ * states).  Every rank still applies the whole circuit to its own copy of the state; the
+ * partial energies are summed by the caller exactly as for term sharding.  Work and memory
+ * traffic of the reduction are 1/world per rank. */
+int vqe_set_amplitude_shard(vqe_t* h, int rank, int world);
 /* host only: the rank that vqe_set_term_shard(.., world) makes responsible for each term
  * (terms sharing an X mask stay together); needs no device */
 int vqe_term_owner(int n_qubits, int n_terms, const uint64_t* xmask, int world, int32_t* owner);

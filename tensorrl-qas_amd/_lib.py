@@ -25,6 +25,7 @@ SIGNATURES = {
     "vqe_set_init_state": (C.c_int, [vp, c_f64p]),
     "vqe_set_hamiltonian_pauli": (C.c_int, [vp, C.c_int, c_u64p, c_u64p, c_f64p]),
     "vqe_set_term_shard": (C.c_int, [vp, C.c_int, C.c_int]),
+    "vqe_set_amplitude_shard": (C.c_int, [vp, C.c_int, C.c_int]),
     "vqe_term_owner": (C.c_int, [C.c_int, C.c_int, c_u64p, C.c_int, c_i32p]),
     "vqe_set_noise": (C.c_int, [vp, C.c_double, C.c_double, C.c_uint64]),
     "vqe_set_circuit": (C.c_int, [vp, C.c_int, c_i32p, c_i32p, c_i32p, c_i32p, C.c_int]),

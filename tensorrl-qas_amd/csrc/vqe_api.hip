@@ -51,6 +51,7 @@ struct vqe_handle {
   std::vector<uint64_t> hx, hz;
   std::vector<double> hcr, hci;
   int shard_rank = 0, shard_world = 1;
+  int amp_rank = 0, amp_world = 1;
   bool ham_set = false;
   DevBuf<uint32_t> d_gx, d_term_z;
   DevBuf<double> d_term_cr, d_term_ci, d_tables;
@@ -306,6 +307,8 @@ BatchArgs make_args(vqe_t* h) {
   A.max_params = h->max_params;
   A.state_out = h->d_state.p;
   A.dbg = h->d_dbg.p;
+  A.amp_rank = h->amp_rank;
+  A.amp_world = h->amp_world;
   return A;
 }
 
@@ -438,7 +441,7 @@ int run(vqe_t* h, int which, double rhobeg, double rhoend, int maxfun) {
     A.new_gate = h->has_new_gate ? h->d_new_gate.p : nullptr;
     if (!h->lds_path) return fail(h, VQE_ESTATE, "the fused env-step launch serves the LDS-resident path (n <= 13)");
   }
-  if (which == 1 && h->shard_world > 1)
+  if (which == 1 && (h->shard_world > 1 || h->amp_world > 1))
     return fail(h, VQE_ESTATE, "term-sharded handles hold partial energies: drive COBYLA with "
                                "vqe_cobyla_ask/tell and sum the partial energies of all ranks");
   if (which == 4 && h->lds_path)
@@ -576,6 +579,18 @@ int vqe_set_term_shard(vqe_t* h, int rank, int world) {
   h->shard_rank = rank;
   h->shard_world = world;
   if (h->ham_set) { HIP_TRY(h, hipSetDevice(h->dev)); return build_hamiltonian(h); }
+  return VQE_OK;
+}
+
+int vqe_set_amplitude_shard(vqe_t* h, int rank, int world) {
+  if (!h) return VQE_EINVAL;
+  if (world < 1 || rank < 0 || rank >= world) return fail(h, VQE_EINVAL, "bad shard rank/world");
+  if (h->lds_path && world > 1)
+    return fail(h, VQE_ESTATE, "amplitude sharding of the energy sweep exists on the streaming path (n >= 14); use vqe_set_term_shard");
+  const size_t blocks = ((size_t)1 << h->n) / (kThreads * kEnergyApt);
+  if (!h->lds_path && (blocks % (size_t)world) != 0) return fail(h, VQE_EINVAL, "world must divide the number of sweep blocks");
+  h->amp_rank = rank;
+  h->amp_world = world;
   return VQE_OK;
 }
 

@@ -94,6 +94,7 @@ struct BatchArgs {
   int maxfun;
   double2* state_out;          // get_state: [2^n]
   unsigned long long* dbg;     // [8] phase cycle counters, written only by -DVQE_STAMPS builds
+  int amp_rank, amp_world;     // streaming path: this handle sweeps slice amp_rank of amp_world of the amplitudes
 };
 
 // ---------------------------------------------------------------------------------------

@@ -176,8 +176,12 @@ __global__ void k_s_terms(BatchArgs A, const uint32_t* masks, const int32_t* met
   }
 }
 
-constexpr int kEnergyApt = 4;  // amplitudes per thread in the energy sweep
+constexpr int kEnergyApt = 4;  // amplitudes (= 2 pairs) per thread in the energy sweep
 
+// <psi|H_shard|psi>, pair based: for every X-mask group each amplitude is read exactly once
+// (as one member of a pair p0 <-> p0 ^ x'), so the sweep moves 16 * 2^n bytes per group and
+// the time of a rank is proportional to the number of groups it owns (the quantity that
+// Pauli-term sharding divides).  Signs are evaluated on the fly from the physical Z masks.
 __global__ void __launch_bounds__(kThreads) k_s_energy(BatchArgs A, const double2* states, int n_terms,
                                                        const uint32_t* gxp, const uint32_t* tzp,
                                                        const double* tsg, double* partial) {
@@ -188,26 +192,39 @@ __global__ void __launch_bounds__(kThreads) k_s_energy(BatchArgs A, const double
   const uint32_t* gx = gxp + (size_t)b * A.ham.n_groups;
   const uint32_t* tz = tzp + (size_t)b * n_terms;
   const double* ts = tsg + (size_t)b * n_terms;
-  const uint32_t base = blockIdx.x * (kThreads * kEnergyApt) + threadIdx.x;
-  double2 own[kEnergyApt];
-#pragma unroll
-  for (int k = 0; k < kEnergyApt; ++k) own[k] = psi[base + k * kThreads];
+  const uint32_t blk = blockIdx.x + (uint32_t)A.amp_rank * gridDim.x;   // this rank's slice of the sweep
+  const uint32_t qbase = blk * (kThreads * (kEnergyApt / 2)) + threadIdx.x;
   double acc = 0.0;
   for (int g = 0; g < A.ham.n_groups; ++g) {
     const uint32_t x = gx[g];
     const int t0 = A.ham.term_off[g], t1 = A.ham.term_off[g + 1];
+    if (x == 0) {   // diagonal group: two neighbouring amplitudes per "pair" slot
 #pragma unroll
-    for (int k = 0; k < kEnergyApt; ++k) {
-      const uint32_t p = base + k * kThreads;
-      const double2 bb = own[k];
-      const double2 a = x ? psi[p ^ x] : bb;
-      double dr = 0.0, di = 0.0;
-      for (int t = t0; t < t1; ++t) {
-        const double s = parity32(p & tz[t]) ? -ts[t] : ts[t];
-        dr += s * A.ham.term_cr[t];
-        di += s * A.ham.term_ci[t];
+      for (int k = 0; k < kEnergyApt / 2; ++k) {
+        const uint32_t p = 2 * (qbase + k * kThreads);
+        const double2 a0 = psi[p], a1 = psi[p + 1];
+        double d0 = 0.0, d1 = 0.0;
+        for (int t = t0; t < t1; ++t) {
+          const double c = ts[t] * A.ham.term_cr[t];
+          d0 += parity32(p & tz[t]) ? -c : c;
+          d1 += parity32((p + 1) & tz[t]) ? -c : c;
+        }
+        acc += (a0.x * a0.x + a0.y * a0.y) * d0 + (a1.x * a1.x + a1.y * a1.y) * d1;
       }
-      acc += (a.x * bb.x + a.y * bb.y) * dr - (a.x * bb.y - a.y * bb.x) * di;
+    } else {
+      const int hb = 31 - __clz((int)x);
+#pragma unroll
+      for (int k = 0; k < kEnergyApt / 2; ++k) {
+        const uint32_t p0 = insert0(qbase + k * kThreads, hb);
+        const double2 bb = psi[p0], a = psi[p0 ^ x];
+        double dr = 0.0, di = 0.0;
+        for (int t = t0; t < t1; ++t) {
+          const double s = parity32(p0 & tz[t]) ? -ts[t] : ts[t];
+          dr += s * A.ham.term_cr[t];
+          di += s * A.ham.term_ci[t];
+        }
+        acc += 2.0 * ((a.x * bb.x + a.y * bb.y) * dr - (a.x * bb.y - a.y * bb.x) * di);
+      }
     }
   }
   const double tot = block_sum(acc, red);
@@ -263,7 +280,7 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
   SW_TRY(sw_reserve(sw.gxp, sw.gxp_cap, (size_t)B * ng));
   SW_TRY(sw_reserve(sw.tzp, sw.tzp_cap, (size_t)B * nt));
   SW_TRY(sw_reserve(sw.tsg, sw.tsg_cap, (size_t)B * nt));
-  const int eblk = (int)(dim / (kThreads * kEnergyApt));
+  const int eblk = (int)(dim / (kThreads * kEnergyApt)) / (A.amp_world > 0 ? A.amp_world : 1);
   SW_TRY(sw_reserve(sw.partial, sw.partial_cap, (size_t)B * eblk));
 
   if (want_circuit) {

@@ -111,6 +111,9 @@ class VQEEngine:
     def set_term_shard(self, rank: int, world: int):
         self._chk(self._lib.vqe_set_term_shard(self._h, int(rank), int(world)))
 
+    def set_amplitude_shard(self, rank: int, world: int):
+        self._chk(self._lib.vqe_set_amplitude_shard(self._h, int(rank), int(world)))
+
     def set_noise(self, p1: float, p2: float, seed: int):
         self._chk(self._lib.vqe_set_noise(self._h, float(p1), float(p2), C.c_uint64(int(seed) & (2 ** 64 - 1))))
 

@@ -70,11 +70,18 @@ class TermShardedEngine:
     """An engine that owns ``rank``'s share of the Pauli terms; ``energies()`` returns the
     all-reduced energies of the resident batch as a device tensor."""
 
-    def __init__(self, engine, rank: int, world: int, device):
+    def __init__(self, engine, rank: int, world: int, device, by_amplitude: bool | None = None):
         import torch
         self.engine, self.rank, self.world = engine, rank, world
         self.device = torch.device(device)
-        engine.set_term_shard(rank, world)
+        # n >= 14: slice the amplitude range (1/world of the sweep per rank, perfectly
+        # balanced); n <= 13: a workgroup holds the whole state, so split the X-mask groups
+        if by_amplitude is None:
+            by_amplitude = not engine.device_info()["lds_path"]
+        if by_amplitude:
+            engine.set_amplitude_shard(rank, world)
+        else:
+            engine.set_term_shard(rank, world)
         self._buf = None
 
     def energies(self, batch: int):

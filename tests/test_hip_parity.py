@@ -388,3 +388,27 @@ def test_edge_cases(tq):
     eng.set_circuit(tq.Circuit(kind, rng.integers(0, n, G), np.full(G, -1), np.arange(G), G))
     with pytest.raises(tq.VQEError):
         eng.energy(np.zeros(G))
+
+
+def test_amplitude_sharding_sums_to_full(tq):
+    """Streaming path: the other partition of the <H> double sum - every rank sweeps 1/world of
+    the basis states for all terms; partial energies add up to the full energy."""
+    n = 15
+    rng = np.random.default_rng(15)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 40, rng, real=False)
+    kind, q0, q1, pidx, th = random_gates(n, 14, rng)
+    eng = _engine(tq, n, psi0, ham)
+    eng.set_circuit(tq.Circuit(kind, q0, q1, pidx, th.size))
+    full = eng.energy(th)
+    assert abs(full - vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th), *ham)) < E_TOL
+    for world in (2, 4, 8):
+        tot = 0.0
+        for r in range(world):
+            eng.set_amplitude_shard(r, world)
+            tot += eng.energy(th)
+        assert abs(tot - full) < E_TOL
+    eng.set_amplitude_shard(0, 1)
+    small = tq.VQEEngine(8)
+    with pytest.raises(tq.VQEError):
+        small.set_amplitude_shard(0, 2)          # LDS-resident sizes shard by X-mask group
