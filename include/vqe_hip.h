@@ -87,6 +87,12 @@ int vqe_term_owner(int n_qubits, int n_terms, const uint64_t* xmask, int world, 
  * semantics: each non-identity Pauli with probability p/3 resp. p/15, one trajectory per
  * evaluation).  The draw for (stream, evaluation, gate) is a pure function of `seed`. */
 int vqe_set_noise(vqe_t* h, double p1, double p2, uint64_t seed);
+/* Finite-shot model of the reference's restricted variant
+ * (environments/VQAs/VQE_qulacs_TN_notin_RL_noise_restricted.py:47-48,84-96): every evaluation
+ * returns E + weights . N(0, sigma^2 I), sigma = n_shots^-1/2, i.e. E + sigma_total * N(0,1)
+ * with sigma_total = sigma * |weights|_2 (the same distribution, one draw per evaluation from
+ * the seeded counter-based generator).  0 switches it off. */
+int vqe_set_shot_noise(vqe_t* h, double sigma_total, uint64_t seed);
 
 /* ---- one circuit ---------------------------------------------------------------------
  * replaces: Parametric_Circuit.construct_ansatz product (the qulacs circuit handle),

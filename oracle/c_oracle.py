@@ -26,6 +26,8 @@ def lib():
         L.orc_evaluate.restype = C.c_double
         L.orc_noise_uniform.argtypes = [C.c_uint64] * 4
         L.orc_noise_uniform.restype = C.c_double
+        L.orc_noise_gauss.argtypes = [C.c_uint64] * 3
+        L.orc_noise_gauss.restype = C.c_double
         L.orc_noise_draws.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, i32p, C.c_double, C.c_double, i32p]
         _lib = L
     return _lib

@@ -125,6 +125,12 @@ double orc_noise_uniform(uint64_t seed, uint64_t b, uint64_t e, uint64_t g) {
   k = mix64(k ^ (g * 0x94D049BB133111EBull));
   return (double)(k >> 11) * (1.0 / 9007199254740992.0);
 }
+/* standard normal for (stream, evaluation): Box-Muller on gate slots 2^40 and 2^40 + 1 */
+double orc_noise_gauss(uint64_t seed, uint64_t b, uint64_t e) {
+  const double u1 = orc_noise_uniform(seed, b, e, (uint64_t)1 << 40);
+  const double u2 = orc_noise_uniform(seed, b, e, ((uint64_t)1 << 40) + 1);
+  return sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586 * u2);
+}
 /* qulacs DepolarizingNoise / TwoQubitDepolarizingNoise draw for every gate of a circuit */
 void orc_noise_draws(uint64_t seed, uint64_t stream, uint64_t eval, int n_gates, const int32_t* kind,
                      double p1, double p2, int32_t* draw) {

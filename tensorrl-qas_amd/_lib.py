@@ -28,6 +28,7 @@ SIGNATURES = {
     "vqe_set_amplitude_shard": (C.c_int, [vp, C.c_int, C.c_int]),
     "vqe_term_owner": (C.c_int, [C.c_int, C.c_int, c_u64p, C.c_int, c_i32p]),
     "vqe_set_noise": (C.c_int, [vp, C.c_double, C.c_double, C.c_uint64]),
+    "vqe_set_shot_noise": (C.c_int, [vp, C.c_double, C.c_uint64]),
     "vqe_set_circuit": (C.c_int, [vp, C.c_int, c_i32p, c_i32p, c_i32p, c_i32p, C.c_int]),
     "vqe_energy": (C.c_int, [vp, c_f64p, c_f64p]),
     "vqe_energy_batch": (C.c_int, [vp, C.c_int, c_f64p, c_f64p]),

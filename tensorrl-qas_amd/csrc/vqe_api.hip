@@ -59,7 +59,7 @@ struct vqe_handle {
 
   DevBuf<int32_t> d_term_off;
   HamDev ham{};
-  NoiseCfg noise{0.0, 0.0, 0ull, 0ull};
+  NoiseCfg noise{0.0, 0.0, 0ull, 0ull, 0.0};
 
   // single circuit
   std::vector<GateRec> circ;
@@ -597,7 +597,15 @@ int vqe_set_amplitude_shard(vqe_t* h, int rank, int world) {
 int vqe_set_noise(vqe_t* h, double p1, double p2, uint64_t seed) {
   if (!h) return VQE_EINVAL;
   if (!(p1 >= 0.0 && p1 <= 1.0 && p2 >= 0.0 && p2 <= 1.0)) return fail(h, VQE_EINVAL, "noise probability outside [0,1]");
-  h->noise = NoiseCfg{p1, p2, seed, 0ull};
+  h->noise = NoiseCfg{p1, p2, seed, 0ull, h->noise.shot_sigma};
+  return VQE_OK;
+}
+
+int vqe_set_shot_noise(vqe_t* h, double sigma_total, uint64_t seed) {
+  if (!h) return VQE_EINVAL;
+  if (!(sigma_total >= 0.0)) return fail(h, VQE_EINVAL, "sigma_total must be >= 0");
+  h->noise.shot_sigma = sigma_total;
+  h->noise.seed = seed;
   return VQE_OK;
 }
 

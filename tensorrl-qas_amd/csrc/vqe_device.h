@@ -66,7 +66,7 @@ struct HamDev {
   const double* term_ci;    // [n_terms]
 };
 
-struct NoiseCfg { double p1, p2; uint64_t seed; uint64_t eval_base; };
+struct NoiseCfg { double p1, p2; uint64_t seed; uint64_t eval_base; double shot_sigma; };
 
 struct BatchArgs {
   int n;                       // qubits
@@ -109,6 +109,14 @@ __device__ __forceinline__ double noise_uniform(uint64_t seed, uint64_t b, uint6
   k = mix64(k ^ (e * 0xBF58476D1CE4E5B9ull));
   k = mix64(k ^ (g * 0x94D049BB133111EBull));
   return (double)(k >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// Standard normal draw for (stream b, evaluation e): Box-Muller on two draws of the same
+// counter-based generator (gate slots 2^40, 2^40+1 are never used by circuits).
+__device__ __forceinline__ double noise_gauss(uint64_t seed, uint64_t b, uint64_t e) {
+  const double u1 = noise_uniform(seed, b, e, (uint64_t)1 << 40);
+  const double u2 = noise_uniform(seed, b, e, ((uint64_t)1 << 40) + 1);
+  return sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586 * u2);
 }
 
 __device__ __forceinline__ uint32_t insert0(uint32_t q, int hb) {
@@ -722,7 +730,8 @@ __global__ void __launch_bounds__(Geo<N>::NT) k_lds_energy(BatchArgs A) {
   const bool noisy = (A.noise.p1 > 0.0 || A.noise.p2 > 0.0);
   stage_groups(A.ham, L);
   compile_all<N>(A, b, noisy ? A.noise.eval_base : 0, L);
-  const double e = lds_evaluate<N>(A, L, A.theta + A.par_begin[b], A.par_count[b]);
+  double e = lds_evaluate<N>(A, L, A.theta + A.par_begin[b], A.par_count[b]);
+  if (A.noise.shot_sigma != 0.0) e += A.noise.shot_sigma * noise_gauss(A.noise.seed, (uint64_t)b, A.noise.eval_base);
   if (threadIdx.x == 0) { A.fout[b] = e; if (A.nfev) A.nfev[b] = 1; }
 }
 
@@ -797,7 +806,9 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
     const uint64_t eid = A.noise.eval_base +
                          (phase == 1 ? (uint64_t)cob.nfvals : (phase == 2 ? (uint64_t)A.maxfun + 1 : 0));
     if (noisy || need_compile) { compile_all<N>(A, b, noisy ? eid : 0, L, sk); need_compile = false; }
-    const double e = lds_evaluate<N>(A, L, th, P, ph);
+    double e = lds_evaluate<N>(A, L, th, P, ph);
+    // finite-shot estimate of <H>: Gaussian with the total standard deviation the caller set
+    if (A.noise.shot_sigma != 0.0) e += A.noise.shot_sigma * noise_gauss(A.noise.seed, (uint64_t)b, eid);
     bool finished_opt = false;
     if (phase == 0) {
       fret = e;

@@ -231,12 +231,14 @@ __global__ void __launch_bounds__(kThreads) k_s_energy(BatchArgs A, const double
   if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(kThreads) k_s_reduce(const double* partial, int nblk, double* fout) {
+__global__ void __launch_bounds__(kThreads) k_s_reduce(const double* partial, int nblk, double* fout,
+                                                       NoiseCfg noise, uint64_t eval_id, int add_shot) {
   __shared__ double red[8];
   const int b = blockIdx.x;
   double acc = 0.0;
   for (int i = threadIdx.x; i < nblk; i += kThreads) acc += partial[(size_t)b * nblk + i];
-  const double tot = block_sum(acc, red);
+  double tot = block_sum(acc, red);
+  if (add_shot && noise.shot_sigma != 0.0) tot += noise.shot_sigma * noise_gauss(noise.seed, (uint64_t)b, eval_id);
   if (threadIdx.x == 0) fout[b] = tot;
 }
 
@@ -297,7 +299,9 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
                        sw.gxp, sw.tzp, sw.tsg);
     hipLaunchKernelGGL(k_s_energy, dim3(eblk, B), dim3(kThreads), 0, st, A, sw.states, n_terms, sw.gxp,
                        sw.tzp, sw.tsg, sw.partial);
-    hipLaunchKernelGGL(k_s_reduce, dim3(B), dim3(kThreads), 0, st, sw.partial, eblk, A.fout);
+    // shot noise belongs to the full energy: only an unsharded handle (or slice 0) adds it
+    hipLaunchKernelGGL(k_s_reduce, dim3(B), dim3(kThreads), 0, st, sw.partial, eblk, A.fout, A.noise, eval_id,
+                       A.amp_rank == 0 ? 1 : 0);
   }
   SW_TRY(hipGetLastError());
   return 0;

@@ -117,6 +117,9 @@ class VQEEngine:
     def set_noise(self, p1: float, p2: float, seed: int):
         self._chk(self._lib.vqe_set_noise(self._h, float(p1), float(p2), C.c_uint64(int(seed) & (2 ** 64 - 1))))
 
+    def set_shot_noise(self, sigma_total: float, seed: int):
+        self._chk(self._lib.vqe_set_shot_noise(self._h, float(sigma_total), C.c_uint64(int(seed) & (2 ** 64 - 1))))
+
     # -- single circuit -------------------------------------------------------------------
     def set_circuit(self, circ: Circuit):
         self._P = circ.n_params

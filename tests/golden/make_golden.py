@@ -178,6 +178,13 @@ def host_fixtures():
         tr.append(c.get_current_threshold())
     cur["moving"] = {"conf": conf, "dones": dones, "trace": tr, "rng_seed": 3}
     out["curricula"] = cur
+    # hexagon-restricted action tables (importable module of the reference)
+    from environments.utils import utils_topology_restrict as rtr
+    out["hexagon"] = {str(n): {str(k): v for k, v in rtr.dictionary_of_actions_hexagon_connectivity(n).items()}
+                      for n in (6, 8, 10)}
+    out["hexagon_reverted"] = {str(n): {str(k): v for k, v in
+                                        rtr.dictionary_of_actions_hexagon_connectivity_reverted(n).items()}
+                               for n in (6, 8, 10)}
     json.dump(out, open(f"{HERE}/host_logic.json", "w"), indent=0, sort_keys=True)
 
 

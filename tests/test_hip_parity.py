@@ -412,3 +412,62 @@ def test_amplitude_sharding_sums_to_full(tq):
     small = tq.VQEEngine(8)
     with pytest.raises(tq.VQEError):
         small.set_amplitude_shard(0, 2)          # LDS-resident sizes shard by X-mask group
+
+
+def test_noise_statistics_match_depolarizing_channels(tq):
+    """Distributional parity of the stochastic noise path (reference
+    VQE_qulacs_TN_notin_RL_noise.py:26-28,40-50; qulacs DepolarizingNoise(q, p) = X, Y, Z with
+    p/3 each, TwoQubitDepolarizingNoise = each of the 15 two-qubit Paulis with p/15): the mean
+    energy over many trajectories equals the exact average over all error patterns."""
+    n = 3
+    rng = np.random.default_rng(5)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 12, rng)
+    kind = np.array([1, 4, 0, 5, 2, 4], np.int32)
+    q0 = np.array([0, 0, 0, 0, 2, 2], np.int32)
+    q1 = np.array([-1, -1, 1, 1, -1, -1], np.int32)
+    pidx = np.array([0, -1, -1, -1, 1, -1], np.int32)
+    th = np.array([0.7, -1.3])
+    p1, p2 = 0.2, 0.4
+    exact = 0.0
+    for d1 in range(4):
+        for d2 in range(16):
+            for d3 in range(4):
+                pr = ((1 - p1) if d1 == 0 else p1 / 3) * ((1 - p2) if d2 == 0 else p2 / 15) * \
+                     ((1 - p1) if d3 == 0 else p1 / 3)
+                dr = np.array([0, d1, 0, d2, 0, d3])
+                exact += pr * vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th, dr), *ham)
+    eng = _engine(tq, n, psi0, ham)
+    eng.set_noise(p1, p2, 424242)
+    eng.set_circuit(tq.Circuit(kind, q0, q1, pidx, 2))
+    samples = np.concatenate([eng.energy_batch(np.tile(th, (4096, 1))) for _ in range(6)])
+    sem = samples.std() / np.sqrt(samples.size)
+    assert abs(samples.mean() - exact) < 5 * sem + 1e-12, (samples.mean(), exact, sem)
+    assert sem > 0
+
+
+def test_shot_noise_matches_restated_generator(tq):
+    """vqe_set_shot_noise: E + sigma_total * N(0,1), the normal draw being a pure function of
+    (seed, stream, evaluation) that the C oracle restates - so noisy energies agree to 1e-10 -
+    and its sample moments are those of the reference's weights . N(0, sigma^2 I)."""
+    import c_oracle as co
+    n = 6
+    rng = np.random.default_rng(31)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 30, rng)
+    kind, q0, q1, pidx, th = random_gates(n, 12, rng)
+    eng = _engine(tq, n, psi0, ham)
+    eng.set_circuit(tq.Circuit(kind, q0, q1, pidx, th.size))
+    clean = eng.energy(th)                                   # evaluation 0, no noise configured
+    sigma_tot, seed = 0.37, 99
+    eng.set_shot_noise(sigma_tot, seed)
+    for e in range(1, 6):
+        got = eng.energy(th)
+        assert abs(got - (clean + sigma_tot * co.lib().orc_noise_gauss(seed, 0, e))) < E_TOL
+    got = eng.energy_batch(np.tile(th, (4096, 1)))           # evaluation 6, streams 0..4095
+    ref = clean + sigma_tot * np.array([co.lib().orc_noise_gauss(seed, b, 6) for b in range(4096)])
+    assert np.abs(got - ref).max() < E_TOL
+    z = (got - clean) / sigma_tot
+    assert abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.std() - 1) < 0.05
+    eng.set_shot_noise(0.0, seed)
+    assert abs(eng.energy(th) - clean) < 1e-13

@@ -178,3 +178,14 @@ def test_batch_generator_shapes():
         if rot[-1]:
             assert b["theta"][b["par_off"][i + 1] - 1] == 0.0
     assert np.array_equal(b["theta"], b["theta"].astype(np.float32).astype(np.float64))
+
+
+def test_hexagon_tables_match_reference():
+    from tensorrl_qas_amd.environments.utils import utils_topology_restrict as tr
+    for n, table in HL["hexagon"].items():
+        got = tr.dictionary_of_actions_hexagon_connectivity(int(n))
+        assert {str(k): v for k, v in got.items()} == table
+    for n, table in HL["hexagon_reverted"].items():
+        got = tr.dictionary_of_actions_hexagon_connectivity_reverted(int(n))
+        assert {str(k): v for k, v in got.items()} == table
+    assert len(tr.dictionary_of_actions_hexagon_connectivity_reverted(8)) == 7      # CNOTs only (reference quirk)
