@@ -723,7 +723,6 @@ struct StagedCobyla {
 // ---- kernels -----------------------------------------------------------------------------
 template <int N>
 __global__ void __launch_bounds__(Geo<N>::NT) k_lds_energy(BatchArgs A) {
-  constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
   const int b = blockIdx.x;

@@ -42,10 +42,6 @@ inline hipError_t sw_reserve(T*& p, size_t& cap, size_t n) {
   return e;
 }
 
-struct GlobalCompileTarget {  // compile_ops writes through the same field names as Lds
-  Op* ops; uint32_t* xm; int32_t* meta;
-};
-
 // one thread per stream: gate list -> ops (+ zm rows, needed to move the Pauli masks)
 __global__ void k_s_compile(BatchArgs A, Op* ops, uint32_t* masks, int32_t* meta, uint64_t eval_id) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
