@@ -106,6 +106,47 @@ def cpu_baseline(tq, ham, psi0, batch, G, n_steps, maxfun):
             "evals_per_s": evals / dt}
 
 
+def episode_aux(tq, torch, dev, num_envs, max_steps):
+    """The named configuration itself: TensorRL_fixed/LIH12q_TNbond2 (137 layers, 110 steps per
+    episode, COBYLA maxiter 1000) through VecCircuitEnv with a uniformly random legal policy -
+    warm-started COBYLA exactly as in the reference's episodes.  Data are the synthetic LiH-12q
+    stand-ins (tensorrl_qas_amd.synthetic).  Reports the wall rate (Python host bookkeeping of
+    every environment included) and the rate of the device part alone."""
+    import copy
+    import tempfile
+    from tensorrl_qas_amd import synthetic
+    from tensorrl_qas_amd.environments.environment_qulacs_TN_notin_agent import CircuitEnv
+    from tensorrl_qas_amd.environments.vec_env import VecCircuitEnv
+    root = synthetic.write_lih12_dataset(tempfile.mkdtemp(prefix="lih12_"))
+    conf = copy.deepcopy(synthetic.LIH12_FIXED_CONFIG)
+    conf["env"]["data_root"] = root
+    vec = VecCircuitEnv(CircuitEnv, conf, torch.device(f"cuda:{dev}"), num_envs)
+    table = vec.envs[0]._actions_table
+    rng = np.random.default_rng(7)
+    vec.reset()
+    n_steps = min(max_steps, vec.envs[0].num_layers_termination)
+    steps = nfev = 0
+    t_gpu = 0.0
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        acts = []
+        for e in vec.envs:
+            ill = set(e.illegal_action_new())
+            a = int(rng.integers(len(table)))
+            while a in ill:
+                a = int(rng.integers(len(table)))
+            acts.append(table[a])
+        vec.step(acts)
+        t_gpu += vec.engine.last_kernel_ms() * 1e-3
+        steps += num_envs
+        nfev += sum(e.nfev for e in vec.envs)
+    dt = time.perf_counter() - t0
+    return {"workload": f"TensorRL_fixed/LIH12q_TNbond2 (synthetic data), {num_envs} envs x {n_steps} steps, random policy",
+            "env_steps_per_s_wall": steps / dt, "env_steps_per_s_device": steps / t_gpu,
+            "mean_nfev_per_step": nfev / steps, "mean_rotations_at_end": float(np.mean(
+                [int((e.state[:, 12:15] == 1).sum()) for e in vec.envs]))}
+
+
 def heis20_aux(tq, torch, dist, rank, world, dev, steps):
     """20-qubit Heisenberg <H>: every rank applies the same circuits, evaluates its share of
     the X-mask groups, one all-reduce (RCCL) sums the partial energies.  Strong scaling of
@@ -171,6 +212,9 @@ def main():
     ap.add_argument("--maxfun", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-heis20", action="store_true")
+    ap.add_argument("--no-episode", action="store_true")
+    ap.add_argument("--episode-envs", type=int, default=512)
+    ap.add_argument("--episode-steps", type=int, default=110)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' "
                     "only to rehearse the multi-rank code path on a box with fewer GPUs than ranks")
@@ -257,6 +301,12 @@ def main():
     warm = {"env_steps_per_s_per_gpu": B / (warm_ms * 1e-3), "mean_nfev": float(nfev_w.mean()),
             "note": "same circuits, x0 = optimum of the previous step (float32), kernel time only"}
 
+    episode = None
+    if not args.no_episode and rank == 0:
+        episode = episode_aux(tq, torch, local, args.episode_envs, args.episode_steps)
+    if world > 1:
+        dist.barrier()
+
     heis = None
     if not args.no_heis20:
         heis = heis20_aux(tq, torch, dist, rank, world, local, max(2, args.steps))
@@ -281,6 +331,8 @@ def main():
                          "note": "state is LDS-resident: algorithmic bytes never reach HBM, frac may exceed 1"},
         }
         out["warm_start"] = warm
+        if episode is not None:
+            out["episode"] = episode
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):      # HBM bytes per launch from a separate rocprofv3 --pmc run
             tr = json.load(open(tfile))

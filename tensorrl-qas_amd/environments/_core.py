@@ -133,6 +133,7 @@ class CircuitEnvBase:
         self.previous_action = [0, 0, 0, 0]
         self.save_circ = 0
         self._actions_table = utils.dictionary_of_actions(n)
+        self._action_index = None
 
         if "non_local_opt" in conf:
             nlo = conf["non_local_opt"]
@@ -275,7 +276,7 @@ class CircuitEnvBase:
             new_idx = -1
         return next_state, circ, ang, new_idx
 
-    def _post_step(self, next_state, circ, x_full, x_opt, energy, nfev, action, train_flag=True):
+    def _post_step(self, next_state, circ, x_full, x_opt, energy, nfev, action, train_flag=True, to_device=True):
         """Commit angles, reward, termination (reference step() :285-333)."""
         n = self.num_qubits
         if len(circ):
@@ -286,7 +287,7 @@ class CircuitEnvBase:
             assert lay.numel() == sel.size
             next_state[lay, n + 3 + ax, qb] = torch.tensor(np.asarray(x_full), dtype=torch.float)
         self.opt_ang_save = x_opt
-        self.state = next_state.clone()
+        self.state = next_state      # (the reference clones once more; nothing aliases it here)
         energy_noiseless = energy
         self.energy = energy
         if energy < self.curriculum.lowest_energy and train_flag:
@@ -308,6 +309,10 @@ class CircuitEnvBase:
             self.curriculum.update_threshold(energy_done=energy_done)
             self.done_threshold = self.curriculum.get_current_threshold()
             self.curriculum_dict[self.current_prob] = copy.deepcopy(self.curriculum)
+        if not to_device:      # VecCircuitEnv moves the whole batch to the device in one copy
+            n3 = self.num_qubits + 3
+            obs = next_state.reshape(-1) if self.state_with_angles else next_state[:, :n3].reshape(-1)
+            return obs, float(rwd), done
         return self._observation(next_state), torch.tensor(rwd, dtype=torch.float32, device=self.device), done
 
     def step(self, action, train_flag=True):
@@ -402,6 +407,12 @@ class CircuitEnvBase:
             if len(slots[i]) == 0:
                 slots[i] = slots[i + 1]
                 slots[i + 1] = []
-        decoded = [key for key, entry in self._actions_table.items() for s in slots if s == entry]
+        # decode: every table key once per slot holding that action, in ascending key order
+        # (what the reference's scan over the whole table produces), via one dict lookup per slot
+        index = getattr(self, "_action_index", None)
+        if index is None or index[0] is not self._actions_table:
+            index = (self._actions_table, {tuple(v): k for k, v in self._actions_table.items()})
+            self._action_index = index
+        decoded = sorted(index[1][tuple(s)] for s in slots if len(s) and tuple(s) in index[1])
         self.illegal_actions = slots
         return decoded

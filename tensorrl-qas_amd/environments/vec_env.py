@@ -47,7 +47,9 @@ class VecCircuitEnv:
         for b, (e, p, a) in enumerate(zip(self.envs, pre, actions)):
             P = p[1].n_params
             o, r, d = e._post_step(p[0], p[1], x[off:off + P], e._strip_new(p[1], p[3], xo[off:off + P]), float(f[b]), int(nfev[b]), a,
-                                   train_flag)
+                                   train_flag, to_device=False)
             off += P
             obs.append(o), rwd.append(r), done.append(d)
-        return torch.stack(obs), torch.stack(rwd), done
+        # one host-to-device copy for the whole batch
+        return (torch.stack(obs).to(self.device),
+                torch.tensor(rwd, dtype=torch.float32).to(self.device), done)
