@@ -212,7 +212,8 @@ def main():
     ap.add_argument("--maxfun", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-heis20", action="store_true")
-    ap.add_argument("--no-episode", action="store_true")
+    ap.add_argument("--episode", action="store_true", help="also run the LIH12q fixed config through "
+                    "VecCircuitEnv (adds launches of the same kernel with other sizes: keep it out of profiled runs)")
     ap.add_argument("--episode-envs", type=int, default=512)
     ap.add_argument("--episode-steps", type=int, default=110)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -302,7 +303,7 @@ def main():
             "note": "same circuits, x0 = optimum of the previous step (float32), kernel time only"}
 
     episode = None
-    if not args.no_episode and rank == 0:
+    if args.episode and rank == 0:
         episode = episode_aux(tq, torch, local, args.episode_envs, args.episode_steps)
     if world > 1:
         dist.barrier()
