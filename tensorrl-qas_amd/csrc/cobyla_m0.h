@@ -40,7 +40,7 @@
 namespace cby {
 
 #if defined(__HIPCC__)
-#define CBY_UNROLL _Pragma("unroll 4")
+#define CBY_UNROLL _Pragma("unroll 8")
 #else
 #define CBY_UNROLL
 #endif
@@ -77,37 +77,65 @@ struct HostCtx {
 
 enum Status { RUNNING = 0, DONE_RHOEND = 1, DONE_MAXFUN = 2, DONE_ROUNDING = 3 };
 
+// Scalars of the optimiser, parked behind the arrays between two calls (save_state /
+// load_state) so that a device kernel holds none of them in registers while it evaluates f.
+constexpr int kStateDoubles = 14;
+
+// Leading dimension of sim / simi: odd, so that walking a matrix along either index touches
+// distinct LDS banks (a stride of n doubles with n = 32 puts a whole column in one bank).
+CBY_HD inline int lead_dim(int n) { return n | 1; }
+
 CBY_HD inline size_t scratch_doubles(int n) {
   // x, sim, simi, datmat, a, vsig, veta, sigbar, dx, w
-  return (size_t)n + (size_t)(n + 1) * n + (size_t)n * n + (size_t)(n + 1) + 6 * (size_t)n + 2;
+  const size_t ld = (size_t)lead_dim(n);
+  return (size_t)n + (size_t)(n + 1) * ld + (size_t)n * ld + (size_t)(n + 1) + 6 * (size_t)n + 2 +
+         kStateDoubles;
 }
 
-template <class Ctx, bool CHECK_INVERSE = false>
+// Real is `double`, or an address-space qualified double (LDS) on the device so that the
+// arrays are reached with ds_ instructions instead of flat ones.
+template <class Ctx, bool CHECK_INVERSE = false, class Real = double>
 struct CobylaM0 {
   Ctx ctx;
-  int n, maxfun;
+  int n, ld, maxfun;
   double rhoend;
   // shared (per problem) arrays
-  double *x, *sim, *simi, *datmat, *a, *vsig, *veta, *sigbar, *dx, *w;
+  Real *x, *sim, *simi, *datmat, *a, *vsig, *veta, *sigbar, *dx, *w, *st;
   // scalars, identical in every thread
   double rho, prerem, parsig, pareta, fbest_ret;
   int nfvals, jdrop, ibrnch, iflag, ifull, status;
 
-  CBY_HD double &SIM(int i, int j) { return sim[(size_t)j * n + i]; }    // coordinate i of vertex j
-  CBY_HD double &SIMI(int j, int i) { return simi[(size_t)j * n + i]; }  // row j of the inverse
+  CBY_HD Real &SIM(int i, int j) { return sim[(size_t)j * ld + i]; }    // coordinate i of vertex j
+  CBY_HD Real &SIMI(int j, int i) { return simi[(size_t)j * ld + i]; }  // row j of the inverse
 
-  CBY_HD void bind(double *mem, int n_) {
+  CBY_HD void bind(Real *mem, int n_) {
     n = n_;
+    ld = lead_dim(n);
     x = mem; mem += n;
-    sim = mem; mem += (size_t)(n + 1) * n;
-    simi = mem; mem += (size_t)n * n;
+    sim = mem; mem += (size_t)(n + 1) * ld;
+    simi = mem; mem += (size_t)n * ld;
     datmat = mem; mem += n + 1;
     a = mem; mem += n;
     vsig = mem; mem += n;
     veta = mem; mem += n;
     sigbar = mem; mem += n;
     dx = mem; mem += n;
-    w = mem;
+    w = mem; mem += n + 2;
+    st = mem;
+  }
+
+  CBY_HD void save_state() {
+    if (ctx.tid == 0) {
+      st[0] = rho; st[1] = prerem; st[2] = parsig; st[3] = pareta; st[4] = fbest_ret; st[5] = rhoend;
+      st[6] = (double)nfvals; st[7] = (double)jdrop; st[8] = (double)ibrnch; st[9] = (double)iflag;
+      st[10] = (double)ifull; st[11] = (double)status; st[12] = (double)maxfun;
+    }
+    ctx.sync();
+  }
+  CBY_HD void load_state() {
+    rho = st[0]; prerem = st[1]; parsig = st[2]; pareta = st[3]; fbest_ret = st[4]; rhoend = st[5];
+    nfvals = (int)st[6]; jdrop = (int)st[7]; ibrnch = (int)st[8]; iflag = (int)st[9];
+    ifull = (int)st[10]; status = (int)st[11]; maxfun = (int)st[12];
   }
 
   // Begin a minimisation; x[] must already hold x0.  Returns 1 when f(x) is wanted.

@@ -124,10 +124,27 @@ __device__ __forceinline__ uint32_t insert0(uint32_t q, int hb) {
 }
 __device__ __forceinline__ int parity32(uint32_t v) { return __popc(v) & 1; }
 
+// Cross-lane moves by DPP (no LDS traffic, unlike ds_bpermute behind __shfl_xor): within a row
+// of 16 lanes the butterfly is quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror,
+// row_mirror; the four row results are then combined through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 // Sum over the NW*64 threads of the block; every thread receives the identical value.
@@ -143,38 +160,35 @@ __device__ __forceinline__ double block_sum(double v, double* red /* >= NW doubl
   return t;
 }
 
-// Workgroup execution context of cobyla_m0.h: strided loops, block-wide reductions.  Sums
-// are taken in a different order than on the host (same algorithm, results differ in the
-// last bits).
-template <int NT>
-struct DevCtx {
-  int tid;
-  double* red;   // >= 12 doubles of LDS (NW sums + NW indices)
-  static constexpr int nth = NT;
-  static constexpr int NW = NT / 64;
-  __device__ void sync() const { __syncthreads(); }
-  __device__ int all_or(int v) const {   // (HIP's __syncthreads_or allocates static LDS)
-    const int any = __ballot(v != 0) != 0ull;
-    int* ired = (int*)(red + NW);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) ired[threadIdx.x >> 6] = any;
-    __syncthreads();
-    int r = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) r |= ired[w];
-    return r != 0;
+// Execution context of cobyla_m0.h on the device: ONE wavefront runs the optimiser's
+// bookkeeping (n <= a few dozen: 64 lanes cover every loop), so its reductions are lane
+// shuffles and its synchronisation points need no s_barrier; the other waves of the workgroup
+// wait at the barrier that follows tell().  Sums are taken in a different order than on the
+// host (same algorithm, results differ in the last bits).
+struct WaveCtx {
+  int tid;   // lane
+  static constexpr int nth = 64;
+  // LDS / global accesses of one wave execute in order; the fence keeps the compiler (and the
+  // memory counters) from moving accesses across the point where lanes exchange data.
+  __device__ void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ int all_or(int v) const {
+    sync();
+    return __ballot(v != 0) != 0ull;
   }
   template <class F>
   __device__ double sum(int n, F f) const {
     double a = 0.0;
-    for (int i = tid; i < n; i += NT) a += f(i);
-    return block_sum<NW>(a, red);
+    for (int i = tid; i < n; i += 64) a += f(i);
+    return wave_sum(a);
   }
   template <class F>
   __device__ int arg_first(int n, F f, double thresh, bool want_max, double* val) const {
     double best = thresh;
     int idx = 0x7fffffff;
-    for (int i = tid; i < n; i += NT) {
+    for (int i = tid; i < n; i += 64) {
       const double v = f(i);
       if (want_max ? (v > best) : (v < best)) { best = v; idx = i; }
     }
@@ -182,19 +196,16 @@ struct DevCtx {
       const bool better = want_max ? (ob > best) : (ob < best);
       if (better || (ob == best && oi < idx)) { best = ob; idx = oi; }
     };
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ob = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(idx, o, 64);
-      merge(ob, oi);
-    }
-    int* ired = (int*)(red + NW);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = best; ired[threadIdx.x >> 6] = idx; }
-    __syncthreads();
-    best = red[0]; idx = ired[0];
-#pragma unroll
-    for (int wv = 1; wv < NW; ++wv) merge(red[wv], ired[wv]);
+    merge(dpp_f64<0xB1>(best), dpp_i32<0xB1>(idx));
+    merge(dpp_f64<0x4E>(best), dpp_i32<0x4E>(idx));
+    merge(dpp_f64<0x141>(best), dpp_i32<0x141>(idx));
+    merge(dpp_f64<0x140>(best), dpp_i32<0x140>(idx));
+    const double b0 = best;
+    const int i0 = idx;
+    best = readlane_f64(b0, 0); idx = __builtin_amdgcn_readlane(i0, 0);
+    merge(readlane_f64(b0, 16), __builtin_amdgcn_readlane(i0, 16));
+    merge(readlane_f64(b0, 32), __builtin_amdgcn_readlane(i0, 32));
+    merge(readlane_f64(b0, 48), __builtin_amdgcn_readlane(i0, 48));
     *val = best;
     return idx == 0x7fffffff ? -1 : idx;
   }
@@ -650,7 +661,7 @@ __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L,
   const long long t0 = clock64();
 #endif
   if constexpr (N >= kRegMinQubits) {
-    run_ops_reg<N>(L, A.init, theta, P, p_hole);
+    run_ops_reg<N>(L, A.init, theta, P, p_hole, A.dbg);
   } else {
     load_init<N>(L, A.init);
     __syncthreads();
@@ -672,50 +683,81 @@ __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L,
 
 // COBYLA with its matrices staged into the state region of LDS while the state is dead
 // (between two evaluations); falls back to the global scratch when they do not fit.
+typedef __attribute__((address_space(3))) double lds_double;
+
 template <int N>
 struct StagedCobyla {
   static constexpr int kThreads = Geo<N>::NT;
-  cby::CobylaM0<DevCtx<Geo<N>::NT>> cob;
-  double* gmem;
-  double* lmem;
-  int words;
+  typedef cby::CobylaM0<WaveCtx, false, lds_double> CobL;   // arrays in LDS (ds_ instructions)
+  typedef cby::CobylaM0<WaveCtx, false, double> CobG;       // arrays in the global scratch
+  double* gmem;    // per-problem scratch; x[] is its first array
+  double* lmem;    // the (dead) state region of LDS
+  int* pub;        // LDS: what wave 0 publishes to the workgroup after a call
+  int n, words;
   bool staged;
-  __device__ void init(double* global_scratch, const Lds& L, int n) {
+  int want, nfvals;   // published after start()/tell()
+  __device__ void init(double* global_scratch, const Lds& L, int n_) {
     gmem = global_scratch;
     lmem = (double*)L.psi;
+    pub = (int*)(L.red + 8);
+    n = n_;
     words = (int)cby::scratch_doubles(n);
     staged = (size_t)words * 8 <= ((size_t)16 << N);
-    cob.ctx.tid = threadIdx.x;
-    cob.ctx.red = L.red;
-    cob.bind(gmem, n);
   }
+  __device__ double* x() const { return gmem; }
+  // the optimiser's scalars as parked in the scratch (valid after start()/tell())
+  __device__ const double* state() const { return gmem + words - cby::kStateDoubles; }
   __device__ void in() {
     if (!staged) return;
     const double2* s = (const double2*)gmem;
     double2* d = (double2*)lmem;
     for (int i = threadIdx.x; i < (words + 1) / 2; i += kThreads) d[i] = s[i];
-    cob.bind(lmem, cob.n);
     __syncthreads();
   }
   __device__ void out() {
-    if (!staged) return;
+    if (threadIdx.x == 0) { pub[0] = want; pub[1] = nfvals; }
     __syncthreads();
+    want = pub[0]; nfvals = pub[1];
+    if (!staged) return;
     const double2* s = (const double2*)lmem;
     double2* d = (double2*)gmem;
     for (int i = threadIdx.x; i < (words + 1) / 2; i += kThreads) d[i] = s[i];
-    cob.bind(gmem, cob.n);
     __syncthreads();
   }
-  __device__ int start(double rhobeg, double rhoend, int maxfun) {
-    in();
-    const int w = cob.start(rhobeg, rhoend, maxfun);
-    out();
-    return w;
+  // FIRST: start() instead of tell().  The optimiser object lives only inside this call.
+  template <bool FIRST, class Cob, class Ptr>
+  __device__ void call(Ptr mem, double f, double rhobeg, double rhoend, int maxfun) {
+    Cob cob;
+    cob.ctx.tid = threadIdx.x & 63;
+    cob.bind(mem, n);
+    if (FIRST) {
+      want = cob.start(rhobeg, rhoend, maxfun);
+    } else {
+      cob.load_state();
+      want = cob.tell(f);
+    }
+    nfvals = cob.nfvals;
+    cob.save_state();
   }
-  __device__ int tell(double f) {
+  template <bool FIRST>
+  __device__ int run(double f, double rhobeg, double rhoend, int maxfun) {
     in();
-    const int w = cob.tell(f);
+    if (threadIdx.x < 64) {
+      if (staged) call<FIRST, CobL>((lds_double*)lmem, f, rhobeg, rhoend, maxfun);
+      else call<FIRST, CobG>(gmem, f, rhobeg, rhoend, maxfun);
+    }
     out();
+    return want;
+  }
+  __device__ int start(double rhobeg, double rhoend, int maxfun) { return run<true>(0.0, rhobeg, rhoend, maxfun); }
+  __device__ int tell(double f, unsigned long long* __restrict__ dbg = nullptr) {
+#ifdef VQE_STAMPS
+    const long long t0 = clock64();
+#endif
+    const int w = run<false>(f, 0.0, 0.0, 0);
+#ifdef VQE_STAMPS
+    if (threadIdx.x == 0) atomicAdd(dbg + 4, (unsigned long long)(clock64() - t0));
+#endif
     return w;
   }
 };
@@ -784,7 +826,6 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
   const int Popt = P - (p_hole >= 0);
   stage_groups(A.ham, L);
   StagedCobyla<N> sc;
-  cby::CobylaM0<DevCtx<Geo<N>::NT>>& cob = sc.cob;
   // phases: 0 = single evaluation (empty x0: scipy returns after one call), 1 = COBYLA loop,
   // 2 = post-action evaluation of env_step.  ONE evaluation call site keeps everything inlined.
   int phase = 0, nfev = 1;
@@ -793,17 +834,17 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
   if (Popt > 0) {
     sc.init(A.scratch + A.scratch_begin[b], L, Popt);
     for (int j = threadIdx.x; j < P; j += kThreads)
-      if (j != p_hole) cob.x[j - (p_hole >= 0 && j > p_hole)] = theta[j];
+      if (j != p_hole) sc.x()[j - (p_hole >= 0 && j > p_hole)] = theta[j];
     __syncthreads();
     sc.start(A.rhobeg, A.rhoend, A.maxfun);   // always asks for f(x0)
     phase = 1;
   }
   for (;;) {
-    const double* th = phase == 0 ? theta : (phase == 1 ? cob.x : xout);
+    const double* th = phase == 0 ? theta : (phase == 1 ? sc.x() : xout);
     const int sk = phase == 2 ? -1 : skip;
     const int ph = phase == 2 ? -1 : p_hole;
     const uint64_t eid = A.noise.eval_base +
-                         (phase == 1 ? (uint64_t)cob.nfvals : (phase == 2 ? (uint64_t)A.maxfun + 1 : 0));
+                         (phase == 1 ? (uint64_t)sc.nfvals : (phase == 2 ? (uint64_t)A.maxfun + 1 : 0));
     if (noisy || need_compile) { compile_all<N>(A, b, noisy ? eid : 0, L, sk); need_compile = false; }
     double e = lds_evaluate<N>(A, L, th, P, ph);
     // finite-shot estimate of <H>: Gaussian with the total standard deviation the caller set
@@ -821,18 +862,19 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
 #ifdef VQE_STAMPS
       const long long tt0 = clock64();
 #endif
-      const int want = sc.tell(e);
+      const int want = sc.tell(e, A.dbg);
 #ifdef VQE_STAMPS
       if (threadIdx.x == 0) atomicAdd(A.dbg + 3, (unsigned long long)(clock64() - tt0));
 #endif
       if (!want) {
         for (int j = threadIdx.x; j < P; j += kThreads) {
-          const double v = (j == p_hole) ? theta[j] : cob.x[j - (p_hole >= 0 && j > p_hole)];
+          const double v = (j == p_hole) ? theta[j] : sc.x()[j - (p_hole >= 0 && j > p_hole)];
           xout[j] = A.env_step ? (double)(float)v : v;
           A.xraw[A.par_begin[b] + j] = v;
         }
-        fret = (cob.status == cby::DONE_RHOEND && cob.ifull == 1) ? flast : cob.fbest_ret;
-        nfev = cob.nfvals;
+        const double* st = sc.state();
+        fret = ((int)st[11] == cby::DONE_RHOEND && (int)st[10] == 1) ? flast : st[4];
+        nfev = sc.nfvals;
         finished_opt = true;
       }
     } else {

@@ -143,6 +143,25 @@ __device__ __forceinline__ double flip_if(double v, uint32_t w, int r) {
   return __hiloint2double((int)hi, __double2loint(v));
 }
 
+// Two plane rotations  (x, y) <- (c x - s y, c y + s x)  updated IN PLACE.  Written as one asm
+// block with tied operands: left to itself hipcc keeps the old and the new amplitudes in two
+// register sets and copies the whole state (2^R v_mov_b64 per gate) where the switch cases
+// merge, which also doubles the register pressure of the loop.
+__device__ __forceinline__ void rot2x2(double& x0, double& y0, double& x1, double& y1, double c, double s0,
+                                       double s1) {
+  double t0, t1;
+  asm("v_mul_f64 %4, %7, %1\n\t"
+      "v_mul_f64 %5, %8, %3\n\t"
+      "v_mul_f64 %1, %6, %1\n\t"
+      "v_mul_f64 %3, %6, %3\n\t"
+      "v_fmac_f64 %1, %7, %0\n\t"
+      "v_fmac_f64 %3, %8, %2\n\t"
+      "v_fma_f64 %0, %6, %0, -%4\n\t"
+      "v_fma_f64 %2, %6, %2, -%5"
+      : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1), "=&v"(t0), "=&v"(t1)
+      : "v"(c), "v"(s0), "v"(s1));
+}
+
 template <int NA, int J>
 __device__ __forceinline__ void rx_pairs(double2 (&amp)[NA], double c, double s) {
   static_assert(J > 0 && J < NA, "partner mask out of range");
@@ -151,9 +170,8 @@ __device__ __forceinline__ void rx_pairs(double2 (&amp)[NA], double c, double s)
   for (int r = 0; r < NA; ++r) {
     if ((r >> HB) & 1) continue;
     const int r2 = r ^ J;
-    const double2 a0 = amp[r], a1 = amp[r2];
-    amp[r] = make_double2(c * a0.x - s * a1.y, c * a0.y + s * a1.x);
-    amp[r2] = make_double2(c * a1.x - s * a0.y, c * a1.y + s * a0.x);
+    // amp[r] = (c a0.x - s a1.y, c a0.y + s a1.x), amp[r2] = (c a1.x - s a0.y, c a1.y + s a0.x)
+    rot2x2(amp[r].x, amp[r2].y, amp[r2].x, amp[r].y, c, s, s);
   }
 }
 
@@ -165,9 +183,8 @@ __device__ __forceinline__ void ry_pairs(double2 (&amp)[NA], double c, double s,
     if ((r >> HB) & 1) continue;
     const int r2 = r ^ J;
     const double s0 = flip_if(s, w, r);
-    const double2 a0 = amp[r], a1 = amp[r2];
-    amp[r] = make_double2(c * a0.x + s0 * a1.x, c * a0.y + s0 * a1.y);
-    amp[r2] = make_double2(c * a1.x - s0 * a0.x, c * a1.y - s0 * a0.y);
+    // amp[r] = c a0 + s0 a1, amp[r2] = c a1 - s0 a0 (componentwise)
+    rot2x2(amp[r2].x, amp[r].x, amp[r2].y, amp[r].y, c, s0, s0);
   }
 }
 
@@ -200,7 +217,11 @@ __device__ __forceinline__ void ry_pairs(double2 (&amp)[NA], double c, double s,
 // LOGICAL order (same contract as run_ops).
 template <int N>
 __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restrict__ init, const double* theta, int P,
-                                   int p_hole = -1) {
+                                   int p_hole = -1, unsigned long long* __restrict__ dbg = nullptr) {
+#ifdef VQE_STAMPS
+  const long long ts0 = clock64();
+  long long trel = 0;
+#endif
   constexpr int kThreads = Geo<N>::NT;
   constexpr int LT = Geo<N>::LT;
   constexpr int R = N - LT;
@@ -225,6 +246,9 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
   uint32_t base = deposit<LT>(tid, L.lay[0].pos, L.lay[0].pos8);
   __syncthreads();   // cs[] visible
   const int nops = L.meta[4];
+#ifdef VQE_STAMPS
+  const long long ts1 = clock64();
+#endif
   // descriptor and (cos, sin) of op o+1 are fetched while op o runs (the sched array has a
   // spare slot; an index outside [0, P) reads entry 0: always valid LDS addresses)
   Op nxt = L.sched[0];
@@ -236,6 +260,9 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
     ncs = L.cs[(unsigned)nxt.pidx < (unsigned)P ? nxt.pidx : 0];
     const int kind = op.kind & 0xff;
     if (kind == OP_RELAYOUT) {
+#ifdef VQE_STAMPS
+      const long long tr0 = clock64();
+#endif
       __syncthreads();                                   // earlier reads of psi are done
 #pragma unroll
       for (int r = 0; r < NA; ++r) L.psi[base ^ combo<R>(e, r)] = amp[r];
@@ -246,6 +273,9 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < NA; ++r) amp[r] = L.psi[base ^ combo<R>(e, r)];
+#ifdef VQE_STAMPS
+      trel += clock64() - tr0;
+#endif
       continue;
     }
     const int inv = (op.kind >> 8) & 1;
@@ -257,16 +287,16 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
       VQE_PAIR_SWITCH((int)(op.xm & 0xff), ry_pairs, amp, cs.x, cs.y, w)
     } else if (kind == OP_RZ) {
 #pragma unroll
-      for (int r = 0; r < NA; ++r) {
-        const double s = flip_if(cs.y, w, r);
-        const double2 a = amp[r];
-        amp[r] = make_double2(cs.x * a.x - s * a.y, cs.x * a.y + s * a.x);
-      }
+      for (int r = 0; r < NA; r += 2)
+        rot2x2(amp[r].x, amp[r].y, amp[r + 1].x, amp[r + 1].y, cs.x, flip_if(cs.y, w, r), flip_if(cs.y, w, r + 1));
     } else {  // OP_PZ
 #pragma unroll
       for (int r = 0; r < NA; ++r) amp[r] = make_double2(flip_if(amp[r].x, w, r), flip_if(amp[r].y, w, r));
     }
   }
+#ifdef VQE_STAMPS
+  const long long ts2 = clock64();
+#endif
   // scatter to logical order: i = A * p ^ c, bit q of A*p = parity(zm[q] & p)
   uint32_t ib = (uint32_t)L.meta[1];
   uint32_t ae[5] = {0u, 0u, 0u, 0u, 0u};
@@ -281,6 +311,13 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
 #pragma unroll
   for (int r = 0; r < NA; ++r) L.psi[ib ^ combo<R>(ae, r)] = amp[r];
   __syncthreads();
+#ifdef VQE_STAMPS
+  if (threadIdx.x == 0 && dbg) {
+    atomicAdd(dbg + 5, (unsigned long long)(ts1 - ts0));          // sincos + initial load
+    atomicAdd(dbg + 6, (unsigned long long)trel);                 // re-layouts
+    atomicAdd(dbg + 7, (unsigned long long)(clock64() - ts2));    // final scatter
+  }
+#endif
 }
 
 }  // namespace vqe
