@@ -125,6 +125,91 @@ std::vector<int> assign_groups(const std::vector<uint32_t>& gx, const std::vecto
   return owner;
 }
 
+// ---- canonical index map of the register path -----------------------------------------------
+// p' = M p over GF(2).  The top R rows of M are functionals chosen greedily so that as many X
+// masks as possible have a non-zero image in the register bits (every one of them in the
+// molecular Hamiltonians tried); the lower rows complete M to an invertible matrix with unit
+// vectors.  Pauli masks transform as x' = M x, z' = M^-T z.
+struct IndexMap {
+  int n = 0;
+  uint32_t row[16] = {0};      // rows of M
+  uint32_t inv_col[16] = {0};  // columns of M^-1 (as bit masks over its rows)
+  uint32_t map_x(uint32_t x) const {
+    uint32_t r = 0;
+    for (int i = 0; i < n; ++i) r |= (uint32_t)(__builtin_popcount(row[i] & x) & 1) << i;
+    return r;
+  }
+  uint32_t map_z(uint32_t z) const {
+    uint32_t r = 0;
+    for (int i = 0; i < n; ++i) r |= (uint32_t)(__builtin_popcount(inv_col[i] & z) & 1) << i;
+    return r;
+  }
+};
+
+IndexMap identity_map(int n) {
+  IndexMap m;
+  m.n = n;
+  for (int i = 0; i < n; ++i) m.row[i] = m.inv_col[i] = 1u << i;
+  return m;
+}
+
+IndexMap choose_index_map(int n, int lt, const std::vector<uint32_t>& xs) {
+  IndexMap m;
+  m.n = n;
+  const int R = n - lt;
+  std::vector<uint32_t> rem(xs), rows;     // masks not yet hit / chosen functionals (any order)
+  uint32_t ech[32] = {0};                  // echelon basis of the chosen rows, by highest bit
+  auto independent = [&](uint32_t v) {
+    for (int bit = n - 1; bit >= 0 && v; --bit)
+      if (((v >> bit) & 1u) && ech[bit]) v ^= ech[bit];
+    return v;
+  };
+  auto add_row = [&](uint32_t f) {
+    const uint32_t red = independent(f);
+    ech[31 - __builtin_clz(red)] = red;
+    rows.push_back(f);
+  };
+  for (int i = 0; i < R; ++i) {
+    uint32_t best = 0;
+    int best_hits = -1;
+    if (!rem.empty()) {
+      for (uint32_t f = 1; f < (1u << n); ++f) {
+        int hits = 0;
+        for (uint32_t x : rem) hits += __builtin_popcount(f & x) & 1;
+        if (hits > best_hits && independent(f)) { best_hits = hits; best = f; }
+      }
+    }
+    if (best_hits <= 0) {   // nothing left to hit: any independent unit functional
+      for (int bit = n - 1; bit >= 0; --bit) if (independent(1u << bit)) { best = 1u << bit; break; }
+    }
+    add_row(best);
+    std::vector<uint32_t> keep;
+    for (uint32_t x : rem) if (!(__builtin_popcount(best & x) & 1)) keep.push_back(x);
+    rem.swap(keep);
+  }
+  for (int i = 0; i < R; ++i) m.row[lt + i] = rows[i];
+  int filled = 0;
+  for (int bit = 0; bit < n && filled < lt; ++bit)
+    if (independent(1u << bit)) { add_row(1u << bit); m.row[filled++] = 1u << bit; }
+  // M^-1 by Gauss-Jordan on [M | I] (rows as bit masks)
+  uint32_t a[16], inv[16];
+  for (int i = 0; i < n; ++i) { a[i] = m.row[i]; inv[i] = 1u << i; }
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    while (piv < n && !((a[piv] >> c) & 1u)) ++piv;
+    std::swap(a[c], a[piv]);
+    std::swap(inv[c], inv[piv]);
+    for (int r = 0; r < n; ++r)
+      if (r != c && ((a[r] >> c) & 1u)) { a[r] ^= a[c]; inv[r] ^= inv[c]; }
+  }
+  for (int i = 0; i < n; ++i) {
+    uint32_t col = 0;
+    for (int j = 0; j < n; ++j) col |= ((inv[j] >> i) & 1u) << j;
+    m.inv_col[i] = col;
+  }
+  return m;
+}
+
 // Build (or rebuild after re-sharding) the device Hamiltonian.
 int build_hamiltonian(vqe_t* h) {
   const int n = h->n;
@@ -146,43 +231,61 @@ int build_hamiltonian(vqe_t* h) {
     for (int k : h->group_terms[g]) if (h->hci[k] != 0.0) return true;
     return false;
   };
-  auto rank_of = [&](int g) { return h->gx_all[g] == 0 && !group_has_im(g) ? 0 : (group_has_im(g) ? 2 : 1); };
-  // ... and inside the real section by the top bit of x, so that consecutive groups share
-  // their addressing context (the kernel recomputes it only when that bit changes)
-  auto top_bit = [&](int g) { return h->gx_all[g] ? 31 - __builtin_clz(h->gx_all[g]) : -1; };
+  // register path: canonical index p' = M p (see IndexMap); all masks below are in p'
+  const bool reg_path = h->lds_path && n >= kRegMinQubits;
+  const int lt = n >= 13 ? 9 : 8;      // Geo<N>::LT of the register path
+  IndexMap im = identity_map(n);
+  if (reg_path) {
+    std::vector<uint32_t> xs;
+    for (int g : mine) if (h->gx_all[g] && !group_has_im(g)) xs.push_back(h->gx_all[g]);
+    im = choose_index_map(n, lt, xs);
+  }
+  auto gxm = [&](int g) { return im.map_x(h->gx_all[g]); };
+  // section of a group: 0 diagonal, 1 real with a register bit in x' (register path only),
+  // 2 other real groups, 3 groups that also need an imaginary table
+  auto rank_of = [&](int g) {
+    if (group_has_im(g)) return 3;
+    const uint32_t x = gxm(g);
+    if (x == 0) return 0;
+    return reg_path && (x >> lt) ? 1 : 2;
+  };
+  // ... and inside a section by the top bit of x'
+  auto top_bit = [&](int g) { const uint32_t x = gxm(g); return x ? 31 - __builtin_clz(x) : -1; };
   if (h->lds_path)
     std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) {
       return rank_of(a) != rank_of(b) ? rank_of(a) < rank_of(b) : top_bit(a) > top_bit(b);
     });
-  int has_diag = 0, n_real = 0;
-  auto add_dummy = [&]() {
-    // zero table; same top bit as the last real group so it extends that run (x must keep
-    // its top bit: use exactly that bit)
-    uint32_t xd = 1u;
-    for (size_t i = gx.size(); i-- > 0;) if (gx[i]) { xd = 1u << (31 - __builtin_clz(gx[i])); break; }
+  int has_diag = 0, n_real = 0, n_cls = 0;
+  auto add_dummy = [&](uint32_t xd) {   // zero table: pads a section to a multiple of kEnergyPD
     gx.push_back(xd);
     term_off.push_back((int32_t)term_z.size());
     tab_r.push_back((int32_t)tables.size());
     tab_i.push_back(-1);
     tables.resize(tables.size() + dim / 2, 0.0);
   };
-  bool padded = false;
-  for (int g : mine) {
-    const uint32_t x = h->gx_all[g];
-    const bool has_im = group_has_im(g);
-    if (h->lds_path && !padded && (has_im)) {          // close the real section
-      while (n_real % kEnergyPD) { add_dummy(); ++n_real; }
-      padded = true;
+  int cur_rank = 0;
+  auto enter_section = [&](int rank) {   // rank 4 = end of the list
+    if (h->lds_path) {
+      if (cur_rank <= 1 && rank >= 2) while (n_cls % kEnergyPD) { add_dummy(1u << lt); ++n_cls; ++n_real; }
+      if (cur_rank <= 2 && rank >= 3) while ((n_real - n_cls) % kEnergyPD) { add_dummy(1u); ++n_real; }
     }
+    cur_rank = rank;
+  };
+  for (int g : mine) {
+    const uint32_t x = gxm(g);
+    const bool has_im = group_has_im(g);
+    const int rank = rank_of(g);
+    enter_section(rank);
     gx.push_back(x);
     for (int k : h->group_terms[g]) {
-      term_z.push_back((uint32_t)h->hz[k]);
+      term_z.push_back(im.map_z((uint32_t)h->hz[k]));
       term_cr.push_back(h->hcr[k]);
       term_ci.push_back(h->hci[k]);
     }
     term_off.push_back((int32_t)term_z.size());
     if (h->lds_path) {
-      if (x == 0 && !has_im) has_diag = 1; else if (!has_im) ++n_real;
+      if (rank == 0) has_diag = 1; else if (!has_im) ++n_real;
+      if (rank == 1) ++n_cls;
       const size_t len = x == 0 ? dim : dim / 2;
       const int hb = x == 0 ? 0 : 31 - __builtin_clz(x);
       if (tables.size() + 2 * len > 0x7FFFFFFFu) return fail(h, VQE_EINVAL, "Hamiltonian too large for the LDS-resident path");
@@ -192,13 +295,25 @@ int build_hamiltonian(vqe_t* h) {
       else tab_i.push_back(-1);
       double* tr = tables.data() + tab_r.back();
       double* ti = has_im ? tables.data() + tab_i.back() : nullptr;
+      // index of the pair member that entry q of the table belongs to
+      std::vector<uint32_t> pidx(len);
+      for (size_t q = 0; q < len; ++q) {
+        if (x == 0) pidx[q] = (uint32_t)q;
+        else if (rank == 1) {   // [j/2][tid][j&1] with r = insert0(j, cls), p' = tid | r << lt
+          const int cls = hb - lt;
+          const uint32_t t = (uint32_t)((q >> 1) & (((size_t)1 << lt) - 1));
+          const uint32_t j = (uint32_t)(((q >> (lt + 1)) << 1) | (q & 1));
+          const uint32_t r = ((j >> cls) << (cls + 1)) | (j & ((1u << cls) - 1u));
+          pidx[q] = t | (r << lt);
+        } else {
+          pidx[q] = (uint32_t)(((q >> hb) << (hb + 1)) | (q & (((size_t)1 << hb) - 1)));
+        }
+      }
       for (int k : h->group_terms[g]) {
-        const uint32_t z = (uint32_t)h->hz[k];
+        const uint32_t z = im.map_z((uint32_t)h->hz[k]);
         for (size_t q = 0; q < len; ++q) {
-          const uint32_t p = x == 0 ? (uint32_t)q
-                                    : (uint32_t)(((q >> hb) << (hb + 1)) | (q & (((size_t)1 << hb) - 1)));
           // pair tables carry the factor 2 of the p <-> p^x symmetry
-          const double sgn = ((__builtin_popcount(p & z) & 1) ? -1.0 : 1.0) * (x == 0 ? 1.0 : 2.0);
+          const double sgn = ((__builtin_popcount(pidx[q] & z) & 1) ? -1.0 : 1.0) * (x == 0 ? 1.0 : 2.0);
           tr[q] += sgn * h->hcr[k];
           if (ti) ti[q] += sgn * h->hci[k];
         }
@@ -208,8 +323,7 @@ int build_hamiltonian(vqe_t* h) {
       tab_i.push_back(has_im ? 0 : -1);
     }
   }
-  if (h->lds_path && !padded)
-    while (n_real % kEnergyPD) { add_dummy(); ++n_real; }
+  enter_section(4);
   int rc;
   if ((rc = upload(h, h->d_gx, gx.data(), gx.size()))) return rc;
   if ((rc = upload(h, h->d_tab_r, tab_r.data(), tab_r.size()))) return rc;
@@ -228,6 +342,8 @@ int build_hamiltonian(vqe_t* h) {
   h->ham.tables = h->d_tables.p;
   h->ham.has_diag = has_diag;
   h->ham.n_real = n_real;
+  h->ham.n_cls = n_cls;
+  for (int i = 0; i < 16; ++i) h->ham.mrow[i] = im.row[i];
   h->ham.term_off = h->d_term_off.p;
   h->ham.term_z = h->d_term_z.p;
   h->ham.term_cr = h->d_term_cr.p;

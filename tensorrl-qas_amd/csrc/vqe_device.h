@@ -58,6 +58,11 @@ struct HamDev {
   const double* tables;
   int has_diag;             // 1: group 0 is the diagonal (x == 0) group
   int n_real;               // real-table pair groups incl. zero padding (multiple of kEnergyPD)
+  // register path (10 <= n <= 13): the state is handed to the energy step in the CANONICAL index
+  // p' = M p (GF(2)-linear, chosen by the host so that the X mask of every real group touches one
+  // of the R register bits LT..n-1 of p'); masks and tables below are expressed in p'.
+  int n_cls;                // leading real groups whose x' has a register bit (multiple of kEnergyPD)
+  uint32_t mrow[16];        // row i of M: bit i of p' = parity(mrow[i] & p)
   // streaming path (n >= 14): explicit terms
   int n_terms;              // terms of the groups above
   const int32_t* term_off;  // [n_groups + 1]
@@ -214,6 +219,16 @@ struct WaveCtx {
 // LDS carve-up of one workgroup.
 
 struct GroupMeta { uint32_t x; int32_t hb; int32_t off_r; int32_t off_i; };
+// Per-group addressing record of the register energy path, staged into LDS once per launch
+// (stage_groups): the wave issues ~1 instruction per 4 cycles, so anything recomputed per
+// group - scalar or vector - costs as much as the floating-point work it serves.
+struct ClsMeta {
+  uint32_t xt16;     // (x' & (NT-1)) << 4 : XORed into tid*16
+  int32_t cls;       // highest register bit of x'
+  uint32_t pad0, pad1;
+  uint32_t off[8];   // byte offset of the partner of own amplitude r = insert0(j, cls): (r ^ xr) << (LT+4)
+};
+
 struct LayoutRec;
 struct Lds {
   double2* psi;     // [2^n]  (also: gate staging during compile, COBYLA matrices during tell)
@@ -222,6 +237,7 @@ struct Lds {
   LayoutRec* lay;   // [max_ops+2] layouts (register path)
   double2* cs;      // [max_params] (cos, sin)(theta/2)
   GroupMeta* gm;    // [n_groups]
+  ClsMeta* cm;    // [n_groups] addressing records of the register energy path (n >= 10)
   double* red;      // [16]
   uint32_t* xm;     // [32] columns of A^-1
   uint32_t* zm;     // [32] rows of A
@@ -234,7 +250,7 @@ __host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params, 
   const int ng = n_groups > 0 ? n_groups : 1;
   size_t b = (size_t)16 << n;
   b += n >= 10 ? (size_t)16 * (2 * max_ops + 2) + (size_t)32 * (max_ops + 2) : (size_t)16 * max_ops;
-  b += (size_t)16 * max_params + (size_t)16 * ng;
+  b += (size_t)16 * max_params + (size_t)16 * ng + (n >= 10 ? (size_t)48 * ng : 0);
   return b + 128 + 128 + 128 + 32 + 64;
 }
 
@@ -252,6 +268,7 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, in
   }
   l.cs = (double2*)base; base += (size_t)16 * max_params;
   l.gm = (GroupMeta*)base; base += (size_t)16 * ng;
+  l.cm = (ClsMeta*)base; if (n >= 10) base += (size_t)48 * ng;
   l.red = (double*)base; base += 128;
   l.xm = (uint32_t*)base; base += 128;
   l.zm = (uint32_t*)base; base += 128;
@@ -265,6 +282,24 @@ __device__ __forceinline__ void stage_groups(const HamDev& H, const Lds& L) {
   for (int g = threadIdx.x; g < H.n_groups; g += (int)blockDim.x) {
     const uint32_t x = H.gx[g];
     L.gm[g] = GroupMeta{x, x ? 31 - __clz((int)x) : 0, H.tab_r[g], H.tab_i[g]};
+  }
+}
+
+// Addressing records of the class groups (register energy path); group index relative to the
+// first class group.
+template <int N>
+__device__ __forceinline__ void stage_cls(const HamDev& H, const Lds& L) {
+  constexpr int LT = Geo<N>::LT;
+  constexpr int NP = 1 << (N - LT - 1);
+  for (int i = threadIdx.x; i < H.n_cls; i += (int)blockDim.x) {
+    const uint32_t x = H.gx[i + H.has_diag];
+    const int cls = (31 - __clz((int)x)) - LT;
+    const uint32_t xr = x >> LT;
+    uint32_t* w = (uint32_t*)(L.cm + i);
+    w[0] = (x & ((1u << LT) - 1u)) << 4;
+    w[1] = (uint32_t)cls;
+    w[2] = w[3] = 0u;
+    for (int j = 0; j < 8; ++j) w[4 + j] = j < NP ? ((insert0((uint32_t)j, cls) ^ xr) << (LT + 4)) : 0u;
   }
 }
 
@@ -347,11 +382,30 @@ namespace vqe {
 
 // compile + (n >= 10) schedule for the register-resident path; ends with a barrier
 template <int N>
-__device__ __forceinline__ void compile_all(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip = -1) {
+__device__ __forceinline__ void compile_all(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip = -1,
+                                            bool canonical = true) {
   compile_ops(A, b, eval_id, L, skip);
   if constexpr (N >= kRegMinQubits) {
     if (threadIdx.x == 0) schedule_ops<N>(L);
     __syncthreads();
+    if (canonical) {
+      // the energy step wants the state in canonical order p' = M (A p ^ c): compose M into the
+      // rows of A and into c that the final scatter of run_ops_reg uses
+      uint32_t zrow = 0, cbit = 0;
+      if (threadIdx.x < N) {
+        const uint32_t m = A.ham.mrow[threadIdx.x];
+        for (int q = 0; q < N; ++q) if ((m >> q) & 1u) zrow ^= L.zm[q];
+        cbit = (uint32_t)parity32(m & (uint32_t)L.meta[1]) << threadIdx.x;
+      }
+      // N <= 13 < 64: the contributing threads sit in wave 0
+      uint32_t cnew = cbit;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) cnew |= __shfl_xor(cnew, o, 16);
+      __syncthreads();
+      if (threadIdx.x < N) L.zm[threadIdx.x] = zrow;
+      if (threadIdx.x == 0) L.meta[1] = (int32_t)cnew;
+      __syncthreads();
+    }
   }
 }
 
@@ -511,35 +565,20 @@ constexpr int kEnergyBatch = 4;
     VQE_ENERGY_PAIRS(x, hb, D[k])                                                                  \
   }
 
+// Real-table groups [g0, g1) (g1 - g0 a multiple of kEnergyPD, tables contiguous) with BOTH
+// members of every pair read from LDS.
 template <int N>
-__device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
+__device__ __forceinline__ void energy_real_lds(const Lds& L, const double* __restrict__ tables, int g0, int g1,
+                                                double& acc0, double& acc1) {
   constexpr int kThreads = Geo<N>::NT;   // shadows the default: this kernel family's block size
   constexpr uint32_t DIM = 1u << N;
   constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;   // pairs per thread
-  constexpr int NA = (DIM + kThreads - 1) / kThreads;       // own amplitudes per thread
   constexpr int LT = Geo<N>::LT;
   constexpr int KB = N > LT + 1 ? N - LT - 1 : 0;           // log2(NP)
   constexpr int PD = kEnergyPD;
   constexpr bool FULL = DIM / 2 >= kThreads;                // every thread owns NP pairs
   const uint32_t tid = threadIdx.x;
-  const double* __restrict__ tables = H.tables;
   const unsigned char* psi_b = (const unsigned char*)L.psi;
-  double acc0 = 0.0, acc1 = 0.0;
-  int g0 = 0;
-  if (H.has_diag) {   // diagonal group: full-length table
-    const double* t = tables + L.gm[0].off_r;
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const uint32_t p = tid + (uint32_t)k * kThreads;
-      if (DIM >= kThreads || p < DIM) {
-        const double2 a = L.psi[p];
-        const double v = (a.x * a.x + a.y * a.y) * t[p];
-        if (k & 1) acc1 += v; else acc0 += v;
-      }
-    }
-    g0 = 1;
-  }
-  const int g1 = g0 + H.n_real;        // multiple of PD groups with real tables
   double buf[PD][NP];
   if (g0 < g1) {
 #pragma unroll
@@ -633,8 +672,18 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
       }
     }
   }
-  // groups with imaginary parts (odd number of Y factors): rare, plain loop
-  for (int g = g1; g < H.n_groups; ++g) {
+}
+
+// Groups with imaginary parts (odd number of Y factors): rare, plain loop.
+template <int N>
+__device__ __forceinline__ void energy_imag_lds(const Lds& L, const double* __restrict__ tables, int g1, int g2,
+                                                double& acc0) {
+  constexpr int kThreads = Geo<N>::NT;
+  constexpr uint32_t DIM = 1u << N;
+  constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;
+  constexpr bool FULL = DIM / 2 >= kThreads;
+  const uint32_t tid = threadIdx.x;
+  for (int g = g1; g < g2; ++g) {
     const GroupMeta m = L.gm[g];
     const double* tr = tables + m.off_r;
     const double* ti = tables + m.off_i;
@@ -650,6 +699,202 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
     }
     acc0 += part;   // pair tables hold 2*D
   }
+}
+
+template <int N>
+__device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
+  constexpr int kThreads = Geo<N>::NT;
+  constexpr uint32_t DIM = 1u << N;
+  constexpr int NA = (DIM + kThreads - 1) / kThreads;       // own amplitudes per thread
+  const uint32_t tid = threadIdx.x;
+  const double* __restrict__ tables = H.tables;
+  double acc0 = 0.0, acc1 = 0.0;
+  int g0 = 0;
+  if (H.has_diag) {   // diagonal group: full-length table
+    const double* t = tables + L.gm[0].off_r;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const uint32_t p = tid + (uint32_t)k * kThreads;
+      if (DIM >= kThreads || p < DIM) {
+        const double2 a = L.psi[p];
+        const double v = (a.x * a.x + a.y * a.y) * t[p];
+        if (k & 1) acc1 += v; else acc0 += v;
+      }
+    }
+    g0 = 1;
+  }
+  const int g1 = g0 + H.n_real;        // multiple of PD groups with real tables
+  energy_real_lds<N>(L, tables, g0, g1, acc0, acc1);
+  energy_imag_lds<N>(L, tables, g1, H.n_groups, acc0);
+  return block_sum<Geo<N>::NW>(acc0 + acc1, L.red);
+}
+
+// Register path (n >= 10).  The state arrives in LDS in canonical order p' = tid | r << LT; each
+// thread keeps its 2^R amplitudes own[r] in registers.  For a group whose x' has register bit
+// `cls` (the highest one) the pairs {p', p' ^ x'} are covered exactly once by taking as one
+// member the own amplitudes with bit cls of r clear: only the partner is read from LDS - half
+// the LDS traffic of energy_real_lds, and none for the diagonal group.  Table entry [j][tid]
+// belongs to r = insert0(j, cls).  Same software pipeline as energy_real_lds (half groups,
+// PD-deep table ring, X mask fetched one step ahead); the class dispatch is a wave-uniform
+// switch around the arithmetic only.
+// NP accumulations  acc += (ax*bx + ay*by) * d  as ONE asm block: keeps the per-class bodies of
+// the switch apart (identical C++ bodies are merged behind a register-select PHI = 2^R moves
+// per half group) and leaves no hazard padding between them.
+__device__ __forceinline__ void pair_fma4(double& acc0, double& acc1, const double2& a0, const double2& a1,
+                                          const double2& a2, const double2& a3, const double2 (&b)[4], double d0,
+                                          double d1, double d2, double d3) {
+  double t0, t1, t2, t3;
+  asm("v_mul_f64 %2, %6, %14\n\tv_mul_f64 %3, %8, %16\n\tv_mul_f64 %4, %10, %18\n\tv_mul_f64 %5, %12, %20\n\t"
+      "v_fmac_f64 %2, %7, %15\n\tv_fmac_f64 %3, %9, %17\n\tv_fmac_f64 %4, %11, %19\n\tv_fmac_f64 %5, %13, %21\n\t"
+      "v_fmac_f64 %0, %2, %22\n\tv_fmac_f64 %1, %3, %23\n\tv_fmac_f64 %0, %4, %24\n\tv_fmac_f64 %1, %5, %25"
+      : "+v"(acc0), "+v"(acc1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(a2.x), "v"(a2.y), "v"(a3.x), "v"(a3.y),
+        "v"(b[0].x), "v"(b[0].y), "v"(b[1].x), "v"(b[1].y), "v"(b[2].x), "v"(b[2].y), "v"(b[3].x), "v"(b[3].y),
+        "v"(d0), "v"(d1), "v"(d2), "v"(d3));
+}
+__device__ __forceinline__ void pair_fma2(double& acc0, double& acc1, const double2& a0, const double2& a1,
+                                          const double2 (&b)[2], double d0, double d1) {
+  double t0, t1;
+  asm("v_mul_f64 %2, %4, %8\n\tv_mul_f64 %3, %6, %10\n\t"
+      "v_fmac_f64 %2, %5, %9\n\tv_fmac_f64 %3, %7, %11\n\t"
+      "v_fmac_f64 %0, %2, %12\n\tv_fmac_f64 %1, %3, %13"
+      : "+v"(acc0), "+v"(acc1), "=&v"(t0), "=&v"(t1)
+      : "v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(b[0].x), "v"(b[0].y), "v"(b[1].x), "v"(b[1].y),
+        "v"(d0), "v"(d1));
+}
+__device__ __forceinline__ void pair_fma1(double& acc0, const double2& a0, const double2 (&b)[1], double d0) {
+  double t0;
+  asm("v_mul_f64 %1, %2, %4\n\tv_fmac_f64 %1, %3, %5\n\tv_fmac_f64 %0, %1, %6"
+      : "+v"(acc0), "=&v"(t0) : "v"(a0.x), "v"(a0.y), "v"(b[0].x), "v"(b[0].y), "v"(d0));
+}
+
+// Register path (n >= 10).  The state arrives in LDS in canonical order p' = tid | r << LT; each
+// thread keeps its 2^R amplitudes own[r] in registers.  For a group whose x' has register bit
+// `cls` (the highest one) the pairs {p', p' ^ x'} are covered exactly once by taking as one
+// member the own amplitudes with bit cls of r clear: only the partner is read from LDS - half
+// the LDS traffic of energy_real_lds, and none for the diagonal group.  Table entry
+// [j/2][tid][j&1] belongs to r = insert0(j, cls).  Software pipeline over half groups with a
+// PD-deep table ring as in energy_real_lds; the addressing records (ClsMeta) are fetched from
+// LDS two groups ahead into two alternating register sets; the class dispatch is a
+// wave-uniform switch around the arithmetic only.
+template <int N>
+__device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H) {
+  constexpr int kThreads = Geo<N>::NT;
+  constexpr uint32_t DIM = 1u << N;
+  constexpr int LT = Geo<N>::LT;
+  constexpr int R = N - LT;
+  constexpr int NA = 1 << R;
+  constexpr int NP = NA / 2;
+  constexpr int HP = NP / 2;                 // pairs per half group
+  constexpr int PD = kEnergyPD;
+  static_assert(NP >= 2 && NP <= 8 && PD % 2 == 0, "register energy path: 2..8 pairs per thread");
+  const uint32_t tid = threadIdx.x;
+  const double* __restrict__ tables = H.tables;
+  const unsigned char* psi_b = (const unsigned char*)L.psi;
+  double2 own[NA];
+#pragma unroll
+  for (int r = 0; r < NA; ++r) own[r] = L.psi[tid + (uint32_t)r * kThreads];
+  double acc0 = 0.0, acc1 = 0.0;
+  int g0 = 0;
+  if (H.has_diag) {
+    const double* t = tables + __builtin_amdgcn_readfirstlane(L.gm[0].off_r);
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+      const double v = (own[r].x * own[r].x + own[r].y * own[r].y) * t[tid + (uint32_t)r * kThreads];
+      if (r & 1) acc1 += v; else acc0 += v;
+    }
+    g0 = 1;
+  }
+  const int gc = g0 + H.n_cls;
+  if (g0 < gc) {
+    const int ncls = H.n_cls;
+    double2 buf[PD][NP / 2];
+    const double2* tcls = (const double2*)(tables + __builtin_amdgcn_readfirstlane(L.gm[g0].off_r));
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+      const double2* t = tcls + (size_t)j * (DIM / 4);
+#pragma unroll
+      for (int k = 0; k < NP / 2; ++k) buf[j][k] = t[tid + (uint32_t)k * kThreads];
+    }
+    double2 bA[HP], bB[HP];
+    // addressing records of the group being loaded / the next one: two alternating sets
+    uint2 mh[2];
+    uint4 mo[2][2];
+    const uint32_t tid16 = tid << 4;
+    uint32_t tb;
+    int ccls;
+#define VQE_R_FETCH(S, GI)                                                                         \
+    {                                                                                              \
+      const ClsMeta* cm_ = L.cm + ((GI) < ncls ? (GI) : ncls - 1);                                 \
+      mh[S] = *(const uint2*)cm_;                                                                  \
+      mo[S][0] = *(const uint4*)cm_->off;                                                          \
+      if constexpr (NP > 4) mo[S][1] = *(const uint4*)(cm_->off + 4);                             \
+    }
+#define VQE_R_OFF(S, J) ((J) == 0 ? mo[S][0].x : (J) == 1 ? mo[S][0].y : (J) == 2 ? mo[S][0].z : (J) == 3 ? mo[S][0].w : \
+                         (J) == 4 ? mo[S][1].x : (J) == 5 ? mo[S][1].y : (J) == 6 ? mo[S][1].z : mo[S][1].w)
+#define VQE_R_LOAD(S, HH, PB)                                                                      \
+    _Pragma("unroll") for (int kk = 0; kk < HP; ++kk)                                             \
+      PB[kk] = *(const double2*)(psi_b + (tb + VQE_R_OFF(S, (HH) * HP + kk)));
+#define VQE_R_OWN(C, J) own[(((J) >> (C)) << ((C) + 1)) | ((J) & ((1 << (C)) - 1))]
+#define VQE_R_DV(D, J) (((J) & 1) ? D[(J) / 2].y : D[(J) / 2].x)
+#define VQE_R_COMP_C(C, HH, PB, D)                                                                 \
+    if constexpr (HP == 4)                                                                         \
+      pair_fma4(acc0, acc1, VQE_R_OWN(C, (HH) * 4), VQE_R_OWN(C, (HH) * 4 + 1), VQE_R_OWN(C, (HH) * 4 + 2),     \
+                VQE_R_OWN(C, (HH) * 4 + 3), PB, VQE_R_DV(D, (HH) * 4), VQE_R_DV(D, (HH) * 4 + 1),            \
+                VQE_R_DV(D, (HH) * 4 + 2), VQE_R_DV(D, (HH) * 4 + 3));                                       \
+    else if constexpr (HP == 2)                                                                    \
+      pair_fma2(acc0, acc1, VQE_R_OWN(C, (HH) * 2), VQE_R_OWN(C, (HH) * 2 + 1), PB, VQE_R_DV(D, (HH) * 2),     \
+                VQE_R_DV(D, (HH) * 2 + 1));                                                                  \
+    else                                                                                           \
+      pair_fma1(acc0, VQE_R_OWN(C, (HH)), PB, VQE_R_DV(D, (HH)));
+#define VQE_R_COMP(HH, PB, D)                                                                      \
+    switch (ccls) {                                                                                \
+      case 0: { VQE_R_COMP_C(0, HH, PB, D) } break;                                                \
+      case 1: { VQE_R_COMP_C(1, HH, PB, D) } break;                                                \
+      case 2: if constexpr (R > 2) { VQE_R_COMP_C(2, HH, PB, D) } break;                           \
+      default: if constexpr (R > 3) { VQE_R_COMP_C(3, HH, PB, D) } break;                          \
+    }
+    VQE_R_FETCH(0, 0)
+    VQE_R_FETCH(1, 1)
+    tb = tid16 ^ mh[0].x;
+    VQE_R_LOAD(0, 0, bA)
+    for (int g = 0; g < ncls; g += PD) {
+#pragma unroll
+      for (int j = 0; j < PD; ++j) {
+        constexpr int S0 = 0;   // (set index = j & 1, spelled out below: j is a constant after unrolling)
+        (void)S0;
+        {   // refill the ring slot consumed in the previous step (see energy_real_lds)
+          const int sl = (j + PD - 1) % PD;
+          int gr = (j == 0) ? (g == 0 ? PD - 1 : g - 1 + PD) : g + j - 1 + PD;
+          gr = gr < ncls ? gr : ncls - 1;
+          const double2* t = tcls + (size_t)gr * (DIM / 4);
+#pragma unroll
+          for (int k = 0; k < NP / 2; ++k) buf[sl][k] = t[tid + (uint32_t)k * kThreads];
+        }
+        ccls = __builtin_amdgcn_readfirstlane((int)mh[j & 1].y);
+        VQE_R_LOAD(j & 1, 1, bB)             // second half of group g+j
+        VQE_R_FETCH(j & 1, g + j + 2)        // its record is free now: fetch that of group g+j+2
+        __builtin_amdgcn_sched_barrier(0);
+        VQE_R_COMP(0, bA, buf[j])
+        __builtin_amdgcn_sched_barrier(0);
+        tb = tid16 ^ mh[(j + 1) & 1].x;      // next group (g+j+1)
+        VQE_R_LOAD((j + 1) & 1, 0, bA)       // its first half
+        __builtin_amdgcn_sched_barrier(0);
+        VQE_R_COMP(1, bB, buf[j])
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#undef VQE_R_FETCH
+#undef VQE_R_OFF
+#undef VQE_R_LOAD
+#undef VQE_R_OWN
+#undef VQE_R_DV
+#undef VQE_R_COMP_C
+#undef VQE_R_COMP
+  }
+  const int g1 = g0 + H.n_real;
+  energy_real_lds<N>(L, tables, gc, g1, acc0, acc1);
+  energy_imag_lds<N>(L, tables, g1, H.n_groups, acc0);
   return block_sum<Geo<N>::NW>(acc0 + acc1, L.red);
 }
 
@@ -670,7 +915,8 @@ __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L,
 #ifdef VQE_STAMPS
   const long long t1 = clock64();
 #endif
-  const double e = lds_energy<N>(L, A.ham);
+  double e;
+  if constexpr (N >= kRegMinQubits) e = reg_energy<N>(L, A.ham); else e = lds_energy<N>(L, A.ham);
 #ifdef VQE_STAMPS   // diagnostic build only: cycles per phase, summed over workgroups (thread 0)
   if (threadIdx.x == 0) {
     atomicAdd(A.dbg + 0, 1ull);
@@ -770,6 +1016,7 @@ __global__ void __launch_bounds__(Geo<N>::NT) k_lds_energy(BatchArgs A) {
   const int b = blockIdx.x;
   const bool noisy = (A.noise.p1 > 0.0 || A.noise.p2 > 0.0);
   stage_groups(A.ham, L);
+  if constexpr (N >= 10) stage_cls<N>(A.ham, L);
   compile_all<N>(A, b, noisy ? A.noise.eval_base : 0, L);
   double e = lds_evaluate<N>(A, L, A.theta + A.par_begin[b], A.par_count[b]);
   if (A.noise.shot_sigma != 0.0) e += A.noise.shot_sigma * noise_gauss(A.noise.seed, (uint64_t)b, A.noise.eval_base);
@@ -781,7 +1028,7 @@ __global__ void __launch_bounds__(Geo<N>::NT) k_lds_state(BatchArgs A) {
   constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
-  compile_all<N>(A, 0, A.noise.eval_base, L);
+  compile_all<N>(A, 0, A.noise.eval_base, L, -1, false);   // logical order for the read-out
   if constexpr (N >= kRegMinQubits) {
     run_ops_reg<N>(L, A.init, A.theta + A.par_begin[0], A.par_count[0]);
   } else {
@@ -825,6 +1072,7 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
   }
   const int Popt = P - (p_hole >= 0);
   stage_groups(A.ham, L);
+  if constexpr (N >= 10) stage_cls<N>(A.ham, L);
   StagedCobyla<N> sc;
   // phases: 0 = single evaluation (empty x0: scipy returns after one call), 1 = COBYLA loop,
   // 2 = post-action evaluation of env_step.  ONE evaluation call site keeps everything inlined.
