@@ -737,6 +737,29 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
 // belongs to r = insert0(j, cls).  Same software pipeline as energy_real_lds (half groups,
 // PD-deep table ring, X mask fetched one step ahead); the class dispatch is a wave-uniform
 // switch around the arithmetic only.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const unsigned char lds_cbyte;
+
+// Table reads through a buffer descriptor: one instruction per load (SGPR descriptor + SGPR
+// group offset + loop-invariant VGPR lane offset), no 64-bit address arithmetic per group.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, -1, 0x00020000);
+}
+__device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+  return make_double2(__hiloint2double(v.y, v.x), __hiloint2double(v.w, v.z));
+}
+__device__ __forceinline__ double buf_load_d(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0);
+  return __hiloint2double(v.y, v.x);
+}
+__device__ __forceinline__ double2 lds_load_d2(lds_cbyte* base, uint32_t off) {
+  const d2v_t v = *(const __attribute__((address_space(3))) d2v_t*)(base + off);
+  return make_double2(v.x, v.y);
+}
+
 // NP accumulations  acc += (ax*bx + ay*by) * d  as ONE asm block: keeps the per-class bodies of
 // the switch apart (identical C++ bodies are merged behind a register-select PHI = 2^R moves
 // per half group) and leaves no hazard padding between them.
@@ -790,17 +813,17 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H) {
   static_assert(NP >= 2 && NP <= 8 && PD % 2 == 0, "register energy path: 2..8 pairs per thread");
   const uint32_t tid = threadIdx.x;
   const double* __restrict__ tables = H.tables;
-  const unsigned char* psi_b = (const unsigned char*)L.psi;
+  lds_cbyte* psi_l = (lds_cbyte*)L.psi;
   double2 own[NA];
 #pragma unroll
-  for (int r = 0; r < NA; ++r) own[r] = L.psi[tid + (uint32_t)r * kThreads];
+  for (int r = 0; r < NA; ++r) own[r] = lds_load_d2(psi_l, (tid + (uint32_t)r * kThreads) << 4);
   double acc0 = 0.0, acc1 = 0.0;
   int g0 = 0;
   if (H.has_diag) {
-    const double* t = tables + __builtin_amdgcn_readfirstlane(L.gm[0].off_r);
+    const __amdgpu_buffer_rsrc_t rd = table_rsrc(tables + __builtin_amdgcn_readfirstlane(L.gm[0].off_r));
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
-      const double v = (own[r].x * own[r].x + own[r].y * own[r].y) * t[tid + (uint32_t)r * kThreads];
+      const double v = (own[r].x * own[r].x + own[r].y * own[r].y) * buf_load_d(rd, (tid + (uint32_t)r * kThreads) << 3, 0);
       if (r & 1) acc1 += v; else acc0 += v;
     }
     g0 = 1;
@@ -808,14 +831,16 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H) {
   const int gc = g0 + H.n_cls;
   if (g0 < gc) {
     const int ncls = H.n_cls;
+    constexpr uint32_t GSTRIDE = DIM * 4;   // bytes of one pair table
     double2 buf[PD][NP / 2];
-    const double2* tcls = (const double2*)(tables + __builtin_amdgcn_readfirstlane(L.gm[g0].off_r));
+    const __amdgpu_buffer_rsrc_t rt = table_rsrc(tables + __builtin_amdgcn_readfirstlane(L.gm[g0].off_r));
+    uint32_t voff[NP / 2];
 #pragma unroll
-    for (int j = 0; j < PD; ++j) {
-      const double2* t = tcls + (size_t)j * (DIM / 4);
+    for (int k = 0; k < NP / 2; ++k) voff[k] = (tid + (uint32_t)k * kThreads) << 4;
 #pragma unroll
-      for (int k = 0; k < NP / 2; ++k) buf[j][k] = t[tid + (uint32_t)k * kThreads];
-    }
+    for (int j = 0; j < PD; ++j)
+#pragma unroll
+      for (int k = 0; k < NP / 2; ++k) buf[j][k] = buf_load_d2(rt, voff[k], (uint32_t)j * GSTRIDE);
     double2 bA[HP], bB[HP];
     // addressing records of the group being loaded / the next one: two alternating sets
     uint2 mh[2];
@@ -834,7 +859,7 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H) {
                          (J) == 4 ? mo[S][1].x : (J) == 5 ? mo[S][1].y : (J) == 6 ? mo[S][1].z : mo[S][1].w)
 #define VQE_R_LOAD(S, HH, PB)                                                                      \
     _Pragma("unroll") for (int kk = 0; kk < HP; ++kk)                                             \
-      PB[kk] = *(const double2*)(psi_b + (tb + VQE_R_OFF(S, (HH) * HP + kk)));
+      PB[kk] = lds_load_d2(psi_l, tb + VQE_R_OFF(S, (HH) * HP + kk));
 #define VQE_R_OWN(C, J) own[(((J) >> (C)) << ((C) + 1)) | ((J) & ((1 << (C)) - 1))]
 #define VQE_R_DV(D, J) (((J) & 1) ? D[(J) / 2].y : D[(J) / 2].x)
 #define VQE_R_COMP_C(C, HH, PB, D)                                                                 \
@@ -847,12 +872,15 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H) {
                 VQE_R_DV(D, (HH) * 2 + 1));                                                                  \
     else                                                                                           \
       pair_fma1(acc0, VQE_R_OWN(C, (HH)), PB, VQE_R_DV(D, (HH)));
-#define VQE_R_COMP(HH, PB, D)                                                                      \
-    switch (ccls) {                                                                                \
-      case 0: { VQE_R_COMP_C(0, HH, PB, D) } break;                                                \
-      case 1: { VQE_R_COMP_C(1, HH, PB, D) } break;                                                \
-      case 2: if constexpr (R > 2) { VQE_R_COMP_C(2, HH, PB, D) } break;                           \
-      default: if constexpr (R > 3) { VQE_R_COMP_C(3, HH, PB, D) } break;                          \
+    // one class dispatch per group: first half, loads of the next group's first half, second half
+#define VQE_R_BODY(C, JJ)                                                                          \
+    {                                                                                              \
+      VQE_R_COMP_C(C, 0, bA, buf[JJ])                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+      tb = tid16 ^ mh[((JJ) + 1) & 1].x;                                                           \
+      VQE_R_LOAD(((JJ) + 1) & 1, 0, bA)                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+      VQE_R_COMP_C(C, 1, bB, buf[JJ])                                                              \
     }
     VQE_R_FETCH(0, 0)
     VQE_R_FETCH(1, 1)
@@ -861,26 +889,24 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H) {
     for (int g = 0; g < ncls; g += PD) {
 #pragma unroll
       for (int j = 0; j < PD; ++j) {
-        constexpr int S0 = 0;   // (set index = j & 1, spelled out below: j is a constant after unrolling)
-        (void)S0;
         {   // refill the ring slot consumed in the previous step (see energy_real_lds)
           const int sl = (j + PD - 1) % PD;
           int gr = (j == 0) ? (g == 0 ? PD - 1 : g - 1 + PD) : g + j - 1 + PD;
           gr = gr < ncls ? gr : ncls - 1;
-          const double2* t = tcls + (size_t)gr * (DIM / 4);
+          const uint32_t soff = (uint32_t)gr * GSTRIDE;
 #pragma unroll
-          for (int k = 0; k < NP / 2; ++k) buf[sl][k] = t[tid + (uint32_t)k * kThreads];
+          for (int k = 0; k < NP / 2; ++k) buf[sl][k] = buf_load_d2(rt, voff[k], soff);
         }
         ccls = __builtin_amdgcn_readfirstlane((int)mh[j & 1].y);
         VQE_R_LOAD(j & 1, 1, bB)             // second half of group g+j
         VQE_R_FETCH(j & 1, g + j + 2)        // its record is free now: fetch that of group g+j+2
         __builtin_amdgcn_sched_barrier(0);
-        VQE_R_COMP(0, bA, buf[j])
-        __builtin_amdgcn_sched_barrier(0);
-        tb = tid16 ^ mh[(j + 1) & 1].x;      // next group (g+j+1)
-        VQE_R_LOAD((j + 1) & 1, 0, bA)       // its first half
-        __builtin_amdgcn_sched_barrier(0);
-        VQE_R_COMP(1, bB, buf[j])
+        switch (ccls) {
+          case 0: VQE_R_BODY(0, j) break;
+          case 1: VQE_R_BODY(1, j) break;
+          case 2: if constexpr (R > 2) VQE_R_BODY(2, j) break;
+          default: if constexpr (R > 3) VQE_R_BODY(3, j) break;
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -890,7 +916,7 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H) {
 #undef VQE_R_OWN
 #undef VQE_R_DV
 #undef VQE_R_COMP_C
-#undef VQE_R_COMP
+#undef VQE_R_BODY
   }
   const int g1 = g0 + H.n_real;
   energy_real_lds<N>(L, tables, gc, g1, acc0, acc1);
