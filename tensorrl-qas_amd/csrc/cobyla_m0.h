@@ -26,7 +26,7 @@
 #include <math.h>
 
 #if defined(__HIPCC__)
-#define CBY_HD __host__ __device__
+#define CBY_HD __host__ __device__ __forceinline__
 #else
 #define CBY_HD
 #endif
@@ -37,12 +37,19 @@
 #pragma clang fp contract(off)
 #endif
 
+#ifndef CBY_STAMP
+#define CBY_STAMP(k)
+#define CBY_STAMP_RESET()
+#endif
+
 namespace cby {
 
 #if defined(__HIPCC__)
 #define CBY_UNROLL _Pragma("unroll 8")
+#define CBY_FULL_UNROLL _Pragma("unroll")
 #else
 #define CBY_UNROLL
+#define CBY_FULL_UNROLL
 #endif
 
 // Execution context for the host: one thread, no synchronisation, sums in index order (the
@@ -51,6 +58,8 @@ namespace cby {
 struct HostCtx {
   static constexpr int tid = 0;
   static constexpr int nth = 1;
+  static constexpr int kPad = 1;   // inner loops run to exactly n
+
   CBY_HD void sync() const {}
   CBY_HD int all_or(int v) const { return v; }
   // sum_{i<n} f(i), identical in every thread
@@ -83,13 +92,17 @@ constexpr int kStateDoubles = 14;
 
 // Leading dimension of sim / simi: odd, so that walking a matrix along either index touches
 // distinct LDS banks (a stride of n doubles with n = 32 puts a whole column in one bank).
-CBY_HD inline int lead_dim(int n) { return n | 1; }
+CBY_HD int lead_dim(int nv) { return nv | 1; }
 
-CBY_HD inline size_t scratch_doubles(int n) {
-  // x, sim, simi, datmat, a, vsig, veta, sigbar, dx, w
-  const size_t ld = (size_t)lead_dim(n);
-  return (size_t)n + (size_t)(n + 1) * ld + (size_t)n * ld + (size_t)(n + 1) + 6 * (size_t)n + 2 +
-         kStateDoubles;
+// Parallel contexts run the inner (serial) loops of a row to nv = n rounded up to kPad, in
+// batches of kPad with every load of a batch in flight together; the padding entries are
+// zero and stay zero, dummy vertices n..nv-1 sit between the real ones and the pole (index nv).
+CBY_HD int padded(int n, int pad) { return (n + pad - 1) / pad * pad; }
+
+CBY_HD size_t scratch_doubles(int n, int pad = 8) {
+  // x, sim, simi, datmat, a, vsig, veta, sigbar, dx, w, state
+  const size_t nv = (size_t)padded(n, pad), ld = (size_t)lead_dim((int)nv);
+  return nv + (nv + 1) * ld + nv * ld + (nv + 1) + 6 * nv + 2 + kStateDoubles;
 }
 
 // Real is `double`, or an address-space qualified double (LDS) on the device so that the
@@ -97,7 +110,8 @@ CBY_HD inline size_t scratch_doubles(int n) {
 template <class Ctx, bool CHECK_INVERSE = false, class Real = double>
 struct CobylaM0 {
   Ctx ctx;
-  int n, ld, maxfun;
+  static constexpr int P = Ctx::kPad;   // batch of the inner loops (all loads of a batch, then the arithmetic)
+  int n, nv, ld, maxfun;   // nv: inner-loop bound (n padded to Ctx::kPad) and index of the pole
   double rhoend;
   // shared (per problem) arrays
   Real *x, *sim, *simi, *datmat, *a, *vsig, *veta, *sigbar, *dx, *w, *st;
@@ -110,19 +124,21 @@ struct CobylaM0 {
 
   CBY_HD void bind(Real *mem, int n_) {
     n = n_;
-    ld = lead_dim(n);
-    x = mem; mem += n;
-    sim = mem; mem += (size_t)(n + 1) * ld;
-    simi = mem; mem += (size_t)n * ld;
-    datmat = mem; mem += n + 1;
-    a = mem; mem += n;
-    vsig = mem; mem += n;
-    veta = mem; mem += n;
-    sigbar = mem; mem += n;
-    dx = mem; mem += n;
-    w = mem; mem += n + 2;
+    nv = padded(n, Ctx::kPad);
+    ld = lead_dim(nv);
+    x = mem; mem += nv;
+    sim = mem; mem += (size_t)(nv + 1) * ld;
+    simi = mem; mem += (size_t)nv * ld;
+    datmat = mem; mem += nv + 1;
+    a = mem; mem += nv;
+    vsig = mem; mem += nv;
+    veta = mem; mem += nv;
+    sigbar = mem; mem += nv;
+    dx = mem; mem += nv;
+    w = mem; mem += nv + 2;
     st = mem;
   }
+  CBY_HD size_t words() const { return (size_t)(st - x) + kStateDoubles; }
 
   CBY_HD void save_state() {
     if (ctx.tid == 0) {
@@ -143,13 +159,18 @@ struct CobylaM0 {
     rho = rhobeg; rhoend = rhoend_; maxfun = maxfun_;
     nfvals = 0; ibrnch = 0; iflag = 0; ifull = 1; status = RUNNING; prerem = 0.0;
     const double temp = 1.0 / rho;
+    if (Ctx::kPad > 1) {   // padding entries must read as zero from now on
+      const int total = (int)(st - sim);
+      for (int k = ctx.tid; k < total; k += ctx.nth) sim[k] = 0.0;
+      ctx.sync();
+    }
     for (int i = ctx.tid; i < n; i += ctx.nth) {
-      SIM(i, n) = x[i];
+      SIM(i, nv) = x[i];
       for (int j = 0; j < n; ++j) { SIM(i, j) = 0.0; SIMI(i, j) = 0.0; }
       SIM(i, i) = rho;
       SIMI(i, i) = temp;
     }
-    jdrop = n;
+    jdrop = nv;   // "the pole"
     ctx.sync();
     return request_eval();
   }
@@ -163,8 +184,8 @@ struct CobylaM0 {
 
   CBY_HD int finish(bool keep_x) {
     if (!keep_x) {
-      for (int i = ctx.tid; i < n; i += ctx.nth) x[i] = SIM(i, n);
-      fbest_ret = datmat[n];
+      for (int i = ctx.tid; i < n; i += ctx.nth) x[i] = SIM(i, nv);
+      fbest_ret = datmat[nv];
     }
     ctx.sync();
     return 0;
@@ -240,21 +261,22 @@ struct CobylaM0 {
   // Report f(x) of the point handed out by the previous start()/tell().  Returns 1 when
   // another evaluation (of the new x[]) is wanted, 0 when finished.
   CBY_HD int tell(double f) {
+    CBY_STAMP_RESET();
     int lbl;
     if (ibrnch == 1) {
       lbl = 440;
     } else {
       if (nfvals <= n + 1) {
-        const double fpole = (jdrop < n) ? datmat[n] : 0.0;
+        const double fpole = (jdrop < n) ? datmat[nv] : 0.0;
         ctx.sync();
         if (jdrop < n) {
           if (fpole <= f) {
-            if (ctx.tid == 0) { x[jdrop] = SIM(jdrop, n); datmat[jdrop] = f; }
+            if (ctx.tid == 0) { x[jdrop] = SIM(jdrop, nv); datmat[jdrop] = f; }
           } else {
             if (ctx.tid == 0) {
-              SIM(jdrop, n) = x[jdrop];
+              SIM(jdrop, nv) = x[jdrop];
               datmat[jdrop] = fpole;
-              datmat[n] = f;
+              datmat[nv] = f;
               for (int k = 0; k <= jdrop; ++k) {
                 SIM(jdrop, k) = -rho;
                 double temp = 0.0;
@@ -287,18 +309,23 @@ struct CobylaM0 {
         // ---- identify the optimal vertex and move it to the pole position
         // (the tie rule compares the all-zero constraint violations: never switches)
         double phimin;
-        int nbest = ctx.arg_first(n, [&](int j) { return datmat[j]; }, datmat[n], false, &phimin);
+        int nbest = ctx.arg_first(n, [&](int j) { return datmat[j]; }, datmat[nv], false, &phimin);
         if (nbest < 0) nbest = n;
         ctx.sync();
         if (nbest < n) {
-          if (ctx.tid == 0) { const double t = datmat[n]; datmat[n] = datmat[nbest]; datmat[nbest] = t; }
+          if (ctx.tid == 0) { const double t = datmat[nv]; datmat[nv] = datmat[nbest]; datmat[nbest] = t; }
           for (int i = ctx.tid; i < n; i += ctx.nth) {
             const double temp = SIM(i, nbest);
             SIM(i, nbest) = 0.0;
-            SIM(i, n) += temp;
+            SIM(i, nv) += temp;
             double tempa = 0.0;
-            CBY_UNROLL
-            for (int k = 0; k < n; ++k) { SIM(i, k) -= temp; tempa -= SIMI(k, i); }
+            for (int k0 = 0; k0 < nv; k0 += P) {   // (dummy vertices n..nv-1: harmless)
+              double v[P], u[P];
+              CBY_FULL_UNROLL
+              for (int q = 0; q < P; ++q) { v[q] = SIM(i, k0 + q); u[q] = SIMI(k0 + q, i); }
+              CBY_FULL_UNROLL
+              for (int q = 0; q < P; ++q) { SIM(i, k0 + q) = v[q] - temp; tempa -= u[q]; }
+            }
             w[i] = tempa;  // becomes SIMI(nbest, i); deferred so column sums read old values
           }
           ctx.sync();
@@ -315,27 +342,40 @@ struct CobylaM0 {
             }
           if (ctx.all_or(bad)) { status = DONE_ROUNDING; return finish(false); }
         }
+        CBY_STAMP(3);
         // ---- linear model: a = -grad
-        const double fp = datmat[n];
+        const double fp = datmat[nv];
         for (int i = ctx.tid; i < n; i += ctx.nth) {
           double temp = 0.0;
-          CBY_UNROLL
-          for (int j = 0; j < n; ++j) temp += (datmat[j] - fp) * SIMI(j, i);
+          for (int j0 = 0; j0 < nv; j0 += P) {   // (rows n..nv-1 of simi are zero)
+            double v[P], u[P];
+            CBY_FULL_UNROLL
+            for (int q = 0; q < P; ++q) { v[q] = datmat[j0 + q]; u[q] = SIMI(j0 + q, i); }
+            CBY_FULL_UNROLL
+            for (int q = 0; q < P; ++q) temp += (v[q] - fp) * u[q];
+          }
           a[i] = -temp;
         }
+        CBY_STAMP(4);
         // ---- simplex acceptability
         parsig = 0.25 * rho;
         pareta = 2.1 * rho;
         int flag_bad = 0;
         for (int j = ctx.tid; j < n; j += ctx.nth) {
           double wsig = 0.0, weta = 0.0;
-          CBY_UNROLL
-          for (int i = 0; i < n; ++i) { wsig += SIMI(j, i) * SIMI(j, i); weta += SIM(i, j) * SIM(i, j); }
+          for (int i0 = 0; i0 < nv; i0 += P) {
+            double v[P], u[P];
+            CBY_FULL_UNROLL
+            for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = SIM(i0 + q, j); }
+            CBY_FULL_UNROLL
+            for (int q = 0; q < P; ++q) { wsig += v[q] * v[q]; weta += u[q] * u[q]; }
+          }
           const double vs = 1.0 / sqrt(wsig), ve = sqrt(weta);
           vsig[j] = vs; veta[j] = ve;
           if (vs < parsig || ve > pareta) flag_bad = 1;
         }
         iflag = ctx.all_or(flag_bad) ? 0 : 1;  // all_or synchronises
+        CBY_STAMP(5);
         if (ibrnch == 1 || iflag == 1) { lbl = 370; continue; }
         // ---- geometry step: replace the worst-placed vertex
         double temp;
@@ -354,7 +394,7 @@ struct CobylaM0 {
         }
         ctx.sync();
         update_simi();
-        for (int j = ctx.tid; j < n; j += ctx.nth) x[j] = SIM(j, n) + dx[j];
+        for (int j = ctx.tid; j < n; j += ctx.nth) x[j] = SIM(j, nv) + dx[j];
         ctx.sync();
         return request_eval();  // ibrnch == 0: the value lands in datmat[jdrop]
       }
@@ -367,21 +407,27 @@ struct CobylaM0 {
         // sum = 0 - a.dx accumulated term by term; prerem = parmu*prerec - sum with parmu = 0
         prerem = ctx.sum(n, [&](int i) { return a[i] * dx[i]; });
         ctx.sync();
-        for (int i = ctx.tid; i < n; i += ctx.nth) x[i] = SIM(i, n) + dx[i];
+        for (int i = ctx.tid; i < n; i += ctx.nth) x[i] = SIM(i, nv) + dx[i];
         ibrnch = 1;
         ctx.sync();
+        CBY_STAMP(6);
         return request_eval();
       }
       if (lbl == 440) {
-        const double vmold = datmat[n];
+        const double vmold = datmat[nv];
         trured = vmold - f;
         if (f == vmold) { prerem = 0.0; trured = 0.0; }
         // ---- which vertex (if any) does x(*) replace
         double ratio = (trured <= 0.0) ? 1.0 : 0.0;
         for (int j = ctx.tid; j < n; j += ctx.nth) {
           double t = 0.0;
-          CBY_UNROLL
-          for (int i = 0; i < n; ++i) t += SIMI(j, i) * dx[i];
+          for (int i0 = 0; i0 < nv; i0 += P) {
+            double v[P], u[P];
+            CBY_FULL_UNROLL
+            for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = dx[i0 + q]; }
+            CBY_FULL_UNROLL
+            for (int q = 0; q < P; ++q) t += v[q] * u[q];
+          }
           t = fabs(t);
           w[j] = t;
           sigbar[j] = t * vsig[j];
@@ -389,14 +435,20 @@ struct CobylaM0 {
         ctx.sync();
         int jd = ctx.arg_first(n, [&](int j) { return w[j]; }, ratio, true, &ratio);
         ctx.sync();
+        CBY_STAMP(0);
         for (int j = ctx.tid; j < n; j += ctx.nth) {
           double t = -1.0;
           if (sigbar[j] >= parsig || sigbar[j] >= vsig[j]) {
             t = veta[j];
             if (trured > 0.0) {
               t = 0.0;
-              CBY_UNROLL
-              for (int i = 0; i < n; ++i) { const double d = dx[i] - SIM(i, j); t += d * d; }
+              for (int i0 = 0; i0 < nv; i0 += P) {
+                double v[P], u[P];
+                CBY_FULL_UNROLL
+                for (int q = 0; q < P; ++q) { v[q] = dx[i0 + q]; u[q] = SIM(i0 + q, j); }
+                CBY_FULL_UNROLL
+                for (int q = 0; q < P; ++q) { const double d = v[q] - u[q]; t += d * d; }
+              }
               t = sqrt(t);
             }
           }
@@ -412,7 +464,9 @@ struct CobylaM0 {
         for (int i = ctx.tid; i < n; i += ctx.nth) SIM(i, jdrop) = dx[i];
         if (ctx.tid == 0) datmat[jdrop] = f;
         ctx.sync();
+        CBY_STAMP(1);
         update_simi();
+        CBY_STAMP(2);
         if (trured > 0.0 && trured >= 0.1 * prerem) { lbl = 140; continue; }
         lbl = 550;
         continue;
@@ -439,10 +493,20 @@ struct CobylaM0 {
     for (int j = ctx.tid; j < n; j += ctx.nth) {
       if (j == jdrop) continue;
       double t = 0.0;
-      CBY_UNROLL
-      for (int i = 0; i < n; ++i) t += SIMI(j, i) * dx[i];
-      CBY_UNROLL
-      for (int i = 0; i < n; ++i) SIMI(j, i) -= t * SIMI(jdrop, i);
+      for (int i0 = 0; i0 < nv; i0 += P) {
+        double v[P], u[P];
+        CBY_FULL_UNROLL
+        for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = dx[i0 + q]; }
+        CBY_FULL_UNROLL
+        for (int q = 0; q < P; ++q) t += v[q] * u[q];
+      }
+      for (int i0 = 0; i0 < nv; i0 += P) {
+        double v[P], u[P];
+        CBY_FULL_UNROLL
+        for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = SIMI(jdrop, i0 + q); }
+        CBY_FULL_UNROLL
+        for (int q = 0; q < P; ++q) SIMI(j, i0 + q) = v[q] - t * u[q];
+      }
     }
     ctx.sync();
   }

@@ -82,6 +82,9 @@ struct vqe_handle {
   StreamWork sw;  // streaming-path work buffers
 };
 
+#ifdef VQE_STAMPS
+static unsigned long long cby_out_[8];
+#endif
 namespace {
 
 int fail(vqe_t* h, int code, const std::string& msg) {
@@ -439,7 +442,7 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   int max_ops = 1, max_par = 1;
   for (int b = 0; b < batch; ++b) {
     sbeg[b] = stot;
-    stot += (int64_t)cby::scratch_doubles(pcnt[b]);
+    stot += (int64_t)cby::scratch_doubles(pcnt[b], 8);
     stot = (stot + 1) & ~(int64_t)1;  // keep 16-byte alignment
     max_par = std::max(max_par, (int)pcnt[b]);
     int ops = 0;
@@ -886,6 +889,16 @@ int vqe_debug_counters(vqe_t* h, uint64_t out[8]) {
   HIP_TRY(h, hipSetDevice(h->dev));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(out, h->d_dbg.p, 64, hipMemcpyDeviceToHost));
+#ifdef VQE_STAMPS   // slots 8..15: device-side COBYLA sections
+  {
+    static unsigned long long zero[8] = {0};
+    HIP_TRY(h, hipMemcpyFromSymbol(cby_out_, HIP_SYMBOL(g_cby_dbg), 64));
+    HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(g_cby_dbg), zero, 64));
+    std::fprintf(stderr, "cobyla sections:");
+    for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %llu", cby_out_[i]);
+    std::fprintf(stderr, "\n");
+  }
+#endif
   HIP_TRY(h, hipMemset(h->d_dbg.p, 0, 64));
   return VQE_OK;
 }
@@ -927,7 +940,7 @@ int vqe_cobyla_create(int n, const double* x0, double rhobeg, double rhoend, int
   vqe_cobyla* c = new (std::nothrow) vqe_cobyla;
   if (!c) return VQE_ENOMEM;
   c->n = n;
-  c->mem.assign(cby::scratch_doubles(n) + 8, 0.0);
+  c->mem.assign(cby::scratch_doubles(n, 1) + 8, 0.0);
   c->c.bind(c->mem.data(), n);
   for (int i = 0; i < n; ++i) c->c.x[i] = x0[i];
   if (n == 0) { c->want = 1; c->c.nfvals = 1; c->c.status = cby::RUNNING; }

@@ -20,6 +20,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef VQE_STAMPS   // diagnostic build: cycles between marked points of the device-side COBYLA
+__device__ unsigned long long g_cby_dbg[8];
+__device__ long long g_cby_t0_unused;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CBY_STAMP_RESET() long long cby_t0_ = (long long)__builtin_readcyclecounter(); (void)cby_t0_
+#define CBY_STAMP(k)                                                                               \
+  {                                                                                                \
+    const long long t_ = (long long)__builtin_readcyclecounter();                                  \
+    if (ctx.tid == 0 && Ctx::nth > 1) __hip_atomic_fetch_add(&g_cby_dbg[k], (unsigned long long)(t_ - cby_t0_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    cby_t0_ = (long long)__builtin_readcyclecounter();                                             \
+  }
+#else
+#define CBY_STAMP_RESET()
+#define CBY_STAMP(k)
+#endif
+#endif
 #include "cobyla_m0.h"
 
 namespace vqe {
@@ -173,24 +189,25 @@ __device__ __forceinline__ double block_sum(double v, double* red /* >= NW doubl
 struct WaveCtx {
   int tid;   // lane
   static constexpr int nth = 64;
+  static constexpr int kPad = 8;   // inner loops in batches of 8, matrices zero-padded (cobyla_m0.h)
   // LDS / global accesses of one wave execute in order; the fence keeps the compiler (and the
   // memory counters) from moving accesses across the point where lanes exchange data.
-  __device__ void sync() const {
+  __device__ __forceinline__ void sync() const {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
-  __device__ int all_or(int v) const {
+  __device__ __forceinline__ int all_or(int v) const {
     sync();
     return __ballot(v != 0) != 0ull;
   }
   template <class F>
-  __device__ double sum(int n, F f) const {
+  __device__ __forceinline__ double sum(int n, F f) const {
     double a = 0.0;
     for (int i = tid; i < n; i += 64) a += f(i);
     return wave_sum(a);
   }
   template <class F>
-  __device__ int arg_first(int n, F f, double thresh, bool want_max, double* val) const {
+  __device__ __forceinline__ int arg_first(int n, F f, double thresh, bool want_max, double* val) const {
     double best = thresh;
     int idx = 0x7fffffff;
     for (int i = tid; i < n; i += 64) {
@@ -968,25 +985,25 @@ struct StagedCobyla {
   int n, words;
   bool staged;
   int want, nfvals;   // published after start()/tell()
-  __device__ void init(double* global_scratch, const Lds& L, int n_) {
+  __device__ __forceinline__ void init(double* global_scratch, const Lds& L, int n_) {
     gmem = global_scratch;
     lmem = (double*)L.psi;
     pub = (int*)(L.red + 8);
     n = n_;
-    words = (int)cby::scratch_doubles(n);
+    words = (int)cby::scratch_doubles(n, WaveCtx::kPad);
     staged = (size_t)words * 8 <= ((size_t)16 << N);
   }
-  __device__ double* x() const { return gmem; }
+  __device__ __forceinline__ double* x() const { return gmem; }
   // the optimiser's scalars as parked in the scratch (valid after start()/tell())
-  __device__ const double* state() const { return gmem + words - cby::kStateDoubles; }
-  __device__ void in() {
+  __device__ __forceinline__ const double* state() const { return gmem + words - cby::kStateDoubles; }
+  __device__ __forceinline__ void in() {
     if (!staged) return;
     const double2* s = (const double2*)gmem;
     double2* d = (double2*)lmem;
     for (int i = threadIdx.x; i < (words + 1) / 2; i += kThreads) d[i] = s[i];
     __syncthreads();
   }
-  __device__ void out() {
+  __device__ __forceinline__ void out() {
     if (threadIdx.x == 0) { pub[0] = want; pub[1] = nfvals; }
     __syncthreads();
     want = pub[0]; nfvals = pub[1];
@@ -998,7 +1015,7 @@ struct StagedCobyla {
   }
   // FIRST: start() instead of tell().  The optimiser object lives only inside this call.
   template <bool FIRST, class Cob, class Ptr>
-  __device__ void call(Ptr mem, double f, double rhobeg, double rhoend, int maxfun) {
+  __device__ __forceinline__ void call(Ptr mem, double f, double rhobeg, double rhoend, int maxfun) {
     Cob cob;
     cob.ctx.tid = threadIdx.x & 63;
     cob.bind(mem, n);
@@ -1012,7 +1029,7 @@ struct StagedCobyla {
     cob.save_state();
   }
   template <bool FIRST>
-  __device__ int run(double f, double rhobeg, double rhoend, int maxfun) {
+  __device__ __forceinline__ int run(double f, double rhobeg, double rhoend, int maxfun) {
     in();
     if (threadIdx.x < 64) {
       if (staged) call<FIRST, CobL>((lds_double*)lmem, f, rhobeg, rhoend, maxfun);
@@ -1021,8 +1038,8 @@ struct StagedCobyla {
     out();
     return want;
   }
-  __device__ int start(double rhobeg, double rhoend, int maxfun) { return run<true>(0.0, rhobeg, rhoend, maxfun); }
-  __device__ int tell(double f, unsigned long long* __restrict__ dbg = nullptr) {
+  __device__ __forceinline__ int start(double rhobeg, double rhoend, int maxfun) { return run<true>(0.0, rhobeg, rhoend, maxfun); }
+  __device__ __forceinline__ int tell(double f, unsigned long long* __restrict__ dbg = nullptr) {
 #ifdef VQE_STAMPS
     const long long t0 = clock64();
 #endif

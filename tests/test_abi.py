@@ -101,3 +101,26 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".h", ".hip")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "vqe_oracle" not in text and "c_oracle" not in text and "oracle/" not in text, fn
+
+
+def test_device_code_has_no_function_calls(tmp_path):
+    """Every device helper must be inlined into its kernel: a real call (s_swappc) loses the LDS
+    address spaces, spills the caller's registers, and under a waves-per-SIMD register cap it
+    once produced a kernel that faulted on the GPU (n = 11 with many parameters)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "tensorrl-qas_amd", "csrc")
+    out = tmp_path / "dev.s"
+    flags = None
+    for line in open(os.path.join(csrc, "Makefile")):
+        if line.startswith("FLAGS :="):
+            flags = line.split(":=", 1)[1].strip().rstrip("\\").split()
+        elif flags is not None and line.startswith(" ") and "-mllvm" in line:
+            flags += line.strip().split()
+    flags = [f for f in flags if f not in ("-shared", "-fPIC")]
+    flags = [f.replace("$(ARCH)", "gfx950") for f in flags]
+    subprocess.run(["/opt/rocm/bin/hipcc", *flags, "--cuda-device-only", "-S",
+                    os.path.join(csrc, "vqe_api.hip"), "-o", str(out)], check=True, capture_output=True)
+    text = out.read_text()
+    assert "k_lds_minimizeILi12" in text
+    assert "s_swappc" not in text and "s_call" not in text

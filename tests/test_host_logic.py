@@ -189,3 +189,16 @@ def test_hexagon_tables_match_reference():
         got = tr.dictionary_of_actions_hexagon_connectivity_reverted(int(n))
         assert {str(k): v for k, v in got.items()} == table
     assert len(tr.dictionary_of_actions_hexagon_connectivity_reverted(8)) == 7      # CNOTs only (reference quirk)
+
+
+def test_cobyla_padded_variant_matches_unpadded(tmp_path):
+    """The device context runs cobyla_m0.h with zero-padded matrices (inner loops in batches of
+    8, pole stored behind the dummy vertices).  Driven serially on the host that variant must
+    give exactly the iterates of the plain one (tests/cpp/cobyla_padding_check.cpp)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "cobyla_padding_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "tensorrl-qas_amd", "csrc"),
+                    os.path.join(root, "tests", "cpp", "cobyla_padding_check.cpp"), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
