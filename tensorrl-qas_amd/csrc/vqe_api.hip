@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -236,7 +237,7 @@ int build_hamiltonian(vqe_t* h) {
   };
   // register path: canonical index p' = M p (see IndexMap); all masks below are in p'
   const bool reg_path = h->lds_path && n >= kRegMinQubits;
-  const int lt = n >= 13 ? 9 : 8;      // Geo<N>::LT of the register path
+  const int lt = n >= kWideMinQubits ? 9 : 8;      // Geo<N>::LT of the register path
   IndexMap im = identity_map(n);
   if (reg_path) {
     std::vector<uint32_t> xs;
@@ -374,7 +375,10 @@ int check_gates(vqe_t* h, int64_t n_gates, const int32_t* kind, const int32_t* q
 
 template <int N>
 int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
-  const size_t lds = lds_bytes(N, A.max_ops, A.max_params, A.ham.n_groups);
+  size_t lds = lds_bytes(N, A.max_ops, A.max_params, A.ham.n_groups);
+#ifdef VQE_STAMPS   // diagnostic build: VQE_LDS_PAD=bytes lowers the workgroups per CU
+  if (const char* pad = std::getenv("VQE_LDS_PAD")) lds += (size_t)std::atol(pad);
+#endif
   if (lds > (size_t)h->lds_per_cu)
     return fail(h, VQE_EINVAL, "circuit too large for the LDS-resident path (gates + parameters)");
   const void* fn = which == 0 ? (const void*)k_lds_energy<N>

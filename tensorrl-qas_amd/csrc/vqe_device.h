@@ -50,10 +50,15 @@ constexpr int kThreads = 256;   // default workgroup size (n <= 11 and the strea
 //    512-thread variant (8 amplitudes per thread, 4 waves per SIMD in 128 VGPRs) was measured
 //    15 % slower: 124 spilled registers and one more re-layout per ~3 rotations;
 //  * n = 13: 512 threads x 16 amplitudes, one workgroup per CU.
+#ifndef VQE_WIDE_MIN
+#define VQE_WIDE_MIN 13
+#endif
+constexpr int kWideMinQubits = VQE_WIDE_MIN;   // 512-thread workgroups from this size on
+
 template <int N>
 struct Geo {
-  static constexpr int NT = N >= 13 ? 512 : 256;   // threads per workgroup
-  static constexpr int LT = N >= 13 ? 9 : 8;       // log2(NT)
+  static constexpr int NT = N >= kWideMinQubits ? 512 : 256;   // threads per workgroup
+  static constexpr int LT = N >= kWideMinQubits ? 9 : 8;       // log2(NT)
   static constexpr int NW = NT / 64;               // waves per workgroup
   static constexpr int WPS = N <= 11 ? 4 : 2;      // waves per SIMD asked of the register allocator
 };

@@ -70,7 +70,21 @@ __device__ __forceinline__ void emit_layout(const Basis& B, LayoutRec* out) {
   out->pos8 = pos8;
 }
 
-// raw ops (L.ops, n = meta[0]) -> scheduled ops (L.sched, n = meta[4]) + layouts (L.lay)
+// bit r of the result = parity(r & svec)
+template <int R>
+__device__ __forceinline__ uint32_t sign_word(uint32_t svec) {
+  constexpr uint32_t pat[5] = {0xAAAAAAAAu, 0xCCCCCCCCu, 0xF0F0F0F0u, 0xFF00FF00u, 0xFFFF0000u};
+  uint32_t w = 0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) if ((svec >> i) & 1u) w ^= pat[i];
+  return w;
+}
+
+// raw ops (L.ops, n = meta[0]) -> scheduled ops (L.sched, n = meta[4]) + layouts (L.lay).
+// Scheduled record: xm = sign word of the op in its layout (bit r: parity of the op's Z mask
+// with register combination r), or the layout index of a RELAYOUT; kind = op | inv << 8 |
+// partner mask j << 16; pidx = BYTE offset of the op's (cos, sin) in L.cs (0 when it has none):
+// everything a thread would otherwise recompute for every evaluation.
 template <int N>
 __device__ __forceinline__ void schedule_ops(const Lds& L) {
   constexpr int R = N - Geo<N>::LT;
@@ -103,8 +117,9 @@ __device__ __forceinline__ void schedule_ops(const Lds& L) {
     }
     uint32_t svec = 0;
     for (int i = 0; i < R; ++i) svec |= (uint32_t)parity32(op.zm & B.e[i]) << i;
-    L.sched[ns++] = Op{j | (svec << 8), op.zm, op.pidx, op.kind};
+    L.sched[ns++] = Op{sign_word<R>(svec), op.zm, op.pidx >= 0 ? op.pidx * 16 : 0, op.kind | (int32_t)(j << 16)};
   }
+  L.sched[ns] = Op{0u, 0u, 0, 0};   // the run loop prefetches one record past the end
   L.meta[4] = ns;
   L.meta[5] = nl;
 }
@@ -125,16 +140,6 @@ __device__ __forceinline__ uint32_t combo(const uint32_t (&e)[5], int r) {
 #pragma unroll
   for (int i = 0; i < R; ++i) if ((r >> i) & 1) v ^= e[i];
   return v;
-}
-
-// bit r of the result = parity(r & svec)
-template <int R>
-__device__ __forceinline__ uint32_t sign_word(uint32_t svec) {
-  constexpr uint32_t pat[5] = {0xAAAAAAAAu, 0xCCCCCCCCu, 0xF0F0F0F0u, 0xFF00FF00u, 0xFFFF0000u};
-  uint32_t w = 0;
-#pragma unroll
-  for (int i = 0; i < R; ++i) if ((svec >> i) & 1u) w ^= pat[i];
-  return w;
 }
 
 __device__ __forceinline__ double flip_if(double v, uint32_t w, int r) {
@@ -244,6 +249,8 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
     for (int r = 0; r < NA; ++r) amp[r] = init[base0 ^ combo<R>(e, r)];
   }
   uint32_t base = deposit<LT>(tid, L.lay[0].pos, L.lay[0].pos8);
+  // all initial amplitudes in: otherwise every case of the gate switch carries its own waits
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __syncthreads();   // cs[] visible
   const int nops = L.meta[4];
 #ifdef VQE_STAMPS
@@ -251,13 +258,14 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
 #endif
   // descriptor and (cos, sin) of op o+1 are fetched while op o runs (the sched array has a
   // spare slot; an index outside [0, P) reads entry 0: always valid LDS addresses)
+  const unsigned char* cs_b = (const unsigned char*)L.cs;
   Op nxt = L.sched[0];
-  double2 ncs = L.cs[(unsigned)nxt.pidx < (unsigned)P ? nxt.pidx : 0];
+  double2 ncs = *(const double2*)(cs_b + nxt.pidx);
   for (int o = 0; o < nops; ++o) {
     const Op op = nxt;
     const double2 cs = ncs;
     nxt = L.sched[o + 1];
-    ncs = L.cs[(unsigned)nxt.pidx < (unsigned)P ? nxt.pidx : 0];
+    ncs = *(const double2*)(cs_b + nxt.pidx);
     const int kind = op.kind & 0xff;
     if (kind == OP_RELAYOUT) {
 #ifdef VQE_STAMPS
@@ -280,11 +288,12 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
     }
     const int inv = (op.kind >> 8) & 1;
     const uint32_t flip = (uint32_t)(parity32(op.zm & base) ^ inv);
-    const uint32_t w = sign_word<R>(op.xm >> 8) ^ (0u - flip);
+    const uint32_t w = op.xm ^ (0u - flip);
+    const int jm = op.kind >> 16;
     if (kind == OP_RX) {
-      VQE_PAIR_SWITCH((int)(op.xm & 0xff), rx_pairs, amp, cs.x, cs.y)
+      VQE_PAIR_SWITCH(jm, rx_pairs, amp, cs.x, cs.y)
     } else if (kind == OP_RY) {
-      VQE_PAIR_SWITCH((int)(op.xm & 0xff), ry_pairs, amp, cs.x, cs.y, w)
+      VQE_PAIR_SWITCH(jm, ry_pairs, amp, cs.x, cs.y, w)
     } else if (kind == OP_RZ) {
 #pragma unroll
       for (int r = 0; r < NA; r += 2)
