@@ -59,6 +59,8 @@ struct HostCtx {
   static constexpr int tid = 0;
   static constexpr int nth = 1;
   static constexpr int kPad = 1;   // inner loops run to exactly n
+  static constexpr bool kSplit = false;   // no second lane to share a row with
+  CBY_HD double pair_sum(double v) const { return v; }
 
   CBY_HD void sync() const {}
   CBY_HD int all_or(int v) const { return v; }
@@ -112,6 +114,11 @@ struct CobylaM0 {
   Ctx ctx;
   static constexpr int P = Ctx::kPad;   // batch of the inner loops (all loads of a batch, then the arithmetic)
   int n, nv, ld, maxfun;   // nv: inner-loop bound (n padded to Ctx::kPad) and index of the pole
+  // Row-parallel loops: this lane works on rows rlane, rlane + rstep, ... and on the part
+  // [ilo, ihi) of each row's inner loop.  Contexts with kSplit put two lanes on a row when all
+  // rows fit in half of the lanes (partial sums are then combined with ctx.pair_sum).
+  int rlane, rstep, ilo, ihi;
+  bool split;
   double rhoend;
   // shared (per problem) arrays
   Real *x, *sim, *simi, *datmat, *a, *vsig, *veta, *sigbar, *dx, *w, *st;
@@ -137,6 +144,15 @@ struct CobylaM0 {
     dx = mem; mem += nv;
     w = mem; mem += nv + 2;
     st = mem;
+    split = Ctx::kSplit && 2 * nv <= ctx.nth;
+    if (split) {
+      const int half = ctx.nth / 2, part = ctx.tid / half;
+      const int mid = ((nv / P + 1) / 2) * P;
+      rlane = ctx.tid % half; rstep = half;
+      ilo = part ? mid : 0; ihi = part ? nv : mid;
+    } else {
+      rlane = ctx.tid; rstep = ctx.nth; ilo = 0; ihi = nv;
+    }
   }
   CBY_HD size_t words() const { return (size_t)(st - x) + kStateDoubles; }
 
@@ -314,18 +330,19 @@ struct CobylaM0 {
         ctx.sync();
         if (nbest < n) {
           if (ctx.tid == 0) { const double t = datmat[nv]; datmat[nv] = datmat[nbest]; datmat[nbest] = t; }
-          for (int i = ctx.tid; i < n; i += ctx.nth) {
+          for (int i = rlane; i < n; i += rstep) {
             const double temp = SIM(i, nbest);
-            SIM(i, nbest) = 0.0;
-            SIM(i, nv) += temp;
+            if (ilo == 0) SIM(i, nv) += temp;
             double tempa = 0.0;
-            for (int k0 = 0; k0 < nv; k0 += P) {   // (dummy vertices n..nv-1: harmless)
+            for (int k0 = ilo; k0 < ihi; k0 += P) {   // (dummy vertices n..nv-1: harmless)
               double v[P], u[P];
               CBY_FULL_UNROLL
               for (int q = 0; q < P; ++q) { v[q] = SIM(i, k0 + q); u[q] = SIMI(k0 + q, i); }
               CBY_FULL_UNROLL
               for (int q = 0; q < P; ++q) { SIM(i, k0 + q) = v[q] - temp; tempa -= u[q]; }
             }
+            if (nbest >= ilo && nbest < ihi) SIM(i, nbest) = -temp;   // (old vertex nbest = new pole: 0 - temp)
+            if (split) tempa = ctx.pair_sum(tempa);
             w[i] = tempa;  // becomes SIMI(nbest, i); deferred so column sums read old values
           }
           ctx.sync();
@@ -345,15 +362,16 @@ struct CobylaM0 {
         CBY_STAMP(3);
         // ---- linear model: a = -grad
         const double fp = datmat[nv];
-        for (int i = ctx.tid; i < n; i += ctx.nth) {
+        for (int i = rlane; i < n; i += rstep) {
           double temp = 0.0;
-          for (int j0 = 0; j0 < nv; j0 += P) {   // (rows n..nv-1 of simi are zero)
+          for (int j0 = ilo; j0 < ihi; j0 += P) {   // (rows n..nv-1 of simi are zero)
             double v[P], u[P];
             CBY_FULL_UNROLL
             for (int q = 0; q < P; ++q) { v[q] = datmat[j0 + q]; u[q] = SIMI(j0 + q, i); }
             CBY_FULL_UNROLL
             for (int q = 0; q < P; ++q) temp += (v[q] - fp) * u[q];
           }
+          if (split) temp = ctx.pair_sum(temp);
           a[i] = -temp;
         }
         CBY_STAMP(4);
@@ -361,15 +379,16 @@ struct CobylaM0 {
         parsig = 0.25 * rho;
         pareta = 2.1 * rho;
         int flag_bad = 0;
-        for (int j = ctx.tid; j < n; j += ctx.nth) {
+        for (int j = rlane; j < n; j += rstep) {
           double wsig = 0.0, weta = 0.0;
-          for (int i0 = 0; i0 < nv; i0 += P) {
+          for (int i0 = ilo; i0 < ihi; i0 += P) {
             double v[P], u[P];
             CBY_FULL_UNROLL
             for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = SIM(i0 + q, j); }
             CBY_FULL_UNROLL
             for (int q = 0; q < P; ++q) { wsig += v[q] * v[q]; weta += u[q] * u[q]; }
           }
+          if (split) { wsig = ctx.pair_sum(wsig); weta = ctx.pair_sum(weta); }
           const double vs = 1.0 / sqrt(wsig), ve = sqrt(weta);
           vsig[j] = vs; veta[j] = ve;
           if (vs < parsig || ve > pareta) flag_bad = 1;
@@ -419,15 +438,16 @@ struct CobylaM0 {
         if (f == vmold) { prerem = 0.0; trured = 0.0; }
         // ---- which vertex (if any) does x(*) replace
         double ratio = (trured <= 0.0) ? 1.0 : 0.0;
-        for (int j = ctx.tid; j < n; j += ctx.nth) {
+        for (int j = rlane; j < n; j += rstep) {
           double t = 0.0;
-          for (int i0 = 0; i0 < nv; i0 += P) {
+          for (int i0 = ilo; i0 < ihi; i0 += P) {
             double v[P], u[P];
             CBY_FULL_UNROLL
             for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = dx[i0 + q]; }
             CBY_FULL_UNROLL
             for (int q = 0; q < P; ++q) t += v[q] * u[q];
           }
+          if (split) t = ctx.pair_sum(t);
           t = fabs(t);
           w[j] = t;
           sigbar[j] = t * vsig[j];
@@ -436,19 +456,20 @@ struct CobylaM0 {
         int jd = ctx.arg_first(n, [&](int j) { return w[j]; }, ratio, true, &ratio);
         ctx.sync();
         CBY_STAMP(0);
-        for (int j = ctx.tid; j < n; j += ctx.nth) {
+        for (int j = rlane; j < n; j += rstep) {
           double t = -1.0;
           if (sigbar[j] >= parsig || sigbar[j] >= vsig[j]) {
             t = veta[j];
             if (trured > 0.0) {
               t = 0.0;
-              for (int i0 = 0; i0 < nv; i0 += P) {
+              for (int i0 = ilo; i0 < ihi; i0 += P) {
                 double v[P], u[P];
                 CBY_FULL_UNROLL
                 for (int q = 0; q < P; ++q) { v[q] = dx[i0 + q]; u[q] = SIM(i0 + q, j); }
                 CBY_FULL_UNROLL
                 for (int q = 0; q < P; ++q) { const double d = v[q] - u[q]; t += d * d; }
               }
+              if (split) t = ctx.pair_sum(t);
               t = sqrt(t);
             }
           }
@@ -490,17 +511,18 @@ struct CobylaM0 {
     ctx.sync();
     for (int i = ctx.tid; i < n; i += ctx.nth) SIMI(jdrop, i) /= temp;
     ctx.sync();
-    for (int j = ctx.tid; j < n; j += ctx.nth) {
+    for (int j = rlane; j < n; j += rstep) {
       if (j == jdrop) continue;
       double t = 0.0;
-      for (int i0 = 0; i0 < nv; i0 += P) {
+      for (int i0 = ilo; i0 < ihi; i0 += P) {
         double v[P], u[P];
         CBY_FULL_UNROLL
         for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = dx[i0 + q]; }
         CBY_FULL_UNROLL
         for (int q = 0; q < P; ++q) t += v[q] * u[q];
       }
-      for (int i0 = 0; i0 < nv; i0 += P) {
+      if (split) t = ctx.pair_sum(t);
+      for (int i0 = ilo; i0 < ihi; i0 += P) {
         double v[P], u[P];
         CBY_FULL_UNROLL
         for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = SIMI(jdrop, i0 + q); }

@@ -900,7 +900,10 @@ int vqe_debug_counters(vqe_t* h, uint64_t out[8]) {
     HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(g_cby_dbg), zero, 64));
     std::fprintf(stderr, "cobyla sections:");
     for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %llu", cby_out_[i]);
-    std::fprintf(stderr, "\n");
+    unsigned long long io[2];
+    HIP_TRY(h, hipMemcpyFromSymbol(io, HIP_SYMBOL(g_cby_in_out), 16));
+    HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(g_cby_in_out), zero, 16));
+    std::fprintf(stderr, " | in %llu out %llu\n", io[0], io[1]);
   }
 #endif
   HIP_TRY(h, hipMemset(h->d_dbg.p, 0, 64));

@@ -22,6 +22,7 @@
 #include <stdint.h>
 #ifdef VQE_STAMPS   // diagnostic build: cycles between marked points of the device-side COBYLA
 __device__ unsigned long long g_cby_dbg[8];
+__device__ unsigned long long g_cby_in_out[2];
 __device__ long long g_cby_t0_unused;
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CBY_STAMP_RESET() long long cby_t0_ = (long long)__builtin_readcyclecounter(); (void)cby_t0_
@@ -195,6 +196,15 @@ struct WaveCtx {
   int tid;   // lane
   static constexpr int nth = 64;
   static constexpr int kPad = 8;   // inner loops in batches of 8, matrices zero-padded (cobyla_m0.h)
+  static constexpr bool kSplit = true;   // <= 32 rows: lanes l and l + 32 share a row
+  // v + (the value of v in lane ^ 32)
+  __device__ __forceinline__ double pair_sum(double v) const {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const bool up = tid >= 32;
+    return v + __hiloint2double(up ? r1[0] : r1[1], up ? r0[0] : r0[1]);
+  }
   // LDS / global accesses of one wave execute in order; the fence keeps the compiler (and the
   // memory counters) from moving accesses across the point where lanes exchange data.
   __device__ __forceinline__ void sync() const {
@@ -822,8 +832,12 @@ __device__ __forceinline__ void pair_fma1(double& acc0, const double2& a0, const
 // PD-deep table ring as in energy_real_lds; the addressing records (ClsMeta) are fetched from
 // LDS two groups ahead into two alternating register sets; the class dispatch is a
 // wave-uniform switch around the arithmetic only.
-template <int N>
-__device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `after_pairs` runs once the class groups are done (the own amplitudes and the table ring are
+// dead from there on): the env-step kernel uses it to start fetching the optimiser's matrices.
+template <int N, class Hook = NoHook>
+__device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H, Hook after_pairs = Hook()) {
   constexpr int kThreads = Geo<N>::NT;
   constexpr uint32_t DIM = 1u << N;
   constexpr int LT = Geo<N>::LT;
@@ -940,6 +954,7 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H) {
 #undef VQE_R_COMP_C
 #undef VQE_R_BODY
   }
+  after_pairs();
   const int g1 = g0 + H.n_real;
   energy_real_lds<N>(L, tables, gc, g1, acc0, acc1);
   energy_imag_lds<N>(L, tables, g1, H.n_groups, acc0);
@@ -947,9 +962,9 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H) {
 }
 
 // One evaluation with the ops already compiled: circuit, then <psi|H|psi>.
-template <int N>
+template <int N, class Hook = NoHook>
 __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L, const double* theta, int P,
-                                               int p_hole = -1) {
+                                               int p_hole = -1, Hook after_pairs = Hook()) {
 #ifdef VQE_STAMPS
   const long long t0 = clock64();
 #endif
@@ -964,7 +979,7 @@ __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L,
   const long long t1 = clock64();
 #endif
   double e;
-  if constexpr (N >= kRegMinQubits) e = reg_energy<N>(L, A.ham); else e = lds_energy<N>(L, A.ham);
+  if constexpr (N >= kRegMinQubits) e = reg_energy<N>(L, A.ham, after_pairs); else e = lds_energy<N>(L, A.ham);
 #ifdef VQE_STAMPS   // diagnostic build only: cycles per phase, summed over workgroups (thread 0)
   if (threadIdx.x == 0) {
     atomicAdd(A.dbg + 0, 1ull);
@@ -1035,12 +1050,28 @@ struct StagedCobyla {
   }
   template <bool FIRST>
   __device__ __forceinline__ int run(double f, double rhobeg, double rhoend, int maxfun) {
+#ifdef VQE_STAMPS
+    const long long t0 = clock64();
+#endif
     in();
+#ifdef VQE_STAMPS
+    const long long t1 = clock64();
+#endif
     if (threadIdx.x < 64) {
       if (staged) call<FIRST, CobL>((lds_double*)lmem, f, rhobeg, rhoend, maxfun);
       else call<FIRST, CobG>(gmem, f, rhobeg, rhoend, maxfun);
     }
+#ifdef VQE_STAMPS
+    const long long t2 = clock64();
+#endif
     out();
+#ifdef VQE_STAMPS
+    if (threadIdx.x == 0 && !FIRST) {
+      atomicAdd(&g_cby_dbg[7], (unsigned long long)(t2 - t1));          // wave 0: load_state + tell + save_state
+      atomicAdd(&g_cby_in_out[0], (unsigned long long)(t1 - t0));       // staging in
+      atomicAdd(&g_cby_in_out[1], (unsigned long long)(clock64() - t2)); // publish + staging out
+    }
+#endif
     return want;
   }
   __device__ __forceinline__ int start(double rhobeg, double rhoend, int maxfun) { return run<true>(0.0, rhobeg, rhoend, maxfun); }
