@@ -120,15 +120,20 @@ def episode_aux(tq, torch, dev, num_envs, max_steps):
     root = synthetic.write_lih12_dataset(tempfile.mkdtemp(prefix="lih12_"))
     conf = copy.deepcopy(synthetic.LIH12_FIXED_CONFIG)
     conf["env"]["data_root"] = root
-    vec = VecCircuitEnv(CircuitEnv, conf, torch.device(f"cuda:{dev}"), num_envs)
-    table = vec.envs[0]._actions_table
+    # two half batches, software pipelined: the host bookkeeping of one overlaps the launch of
+    # the other (VecCircuitEnv.step_async / step_wait; each half has its own engine and stream)
+    half = max(1, num_envs // 2)
+    vecs = [VecCircuitEnv(CircuitEnv, conf, torch.device(f"cuda:{dev}"), half, seed=s) for s in (0, 1)]
+    num_envs = 2 * half
+    table = vecs[0].envs[0]._actions_table
     rng = np.random.default_rng(7)
-    vec.reset()
-    n_steps = min(max_steps, vec.envs[0].num_layers_termination)
+    for v in vecs:
+        v.reset()
+    n_steps = min(max_steps, vecs[0].envs[0].num_layers_termination)
     steps = nfev = 0
     t_gpu = 0.0
-    t0 = time.perf_counter()
-    for _ in range(n_steps):
+
+    def choose(vec):
         acts = []
         for e in vec.envs:
             ill = set(e.illegal_action_new())
@@ -136,15 +141,31 @@ def episode_aux(tq, torch, dev, num_envs, max_steps):
             while a in ill:
                 a = int(rng.integers(len(table)))
             acts.append(table[a])
-        vec.step(acts)
+        return acts
+
+    def collect(vec):
+        nonlocal steps, nfev, t_gpu
+        vec.step_wait()
         t_gpu += vec.engine.last_kernel_ms() * 1e-3
-        steps += num_envs
+        steps += vec.num_envs
         nfev += sum(e.nfev for e in vec.envs)
+
+    t0 = time.perf_counter()
+    vecs[0].step_async(choose(vecs[0]))
+    for it in range(n_steps):
+        vecs[1].step_async(choose(vecs[1]))          # launch B while A runs
+        collect(vecs[0])
+        if it + 1 < n_steps:
+            vecs[0].step_async(choose(vecs[0]))      # launch A's next step while B runs
+        collect(vecs[1])
     dt = time.perf_counter() - t0
-    return {"workload": f"TensorRL_fixed/LIH12q_TNbond2 (synthetic data), {num_envs} envs x {n_steps} steps, random policy",
+    envs = vecs[0].envs + vecs[1].envs
+    return {"workload": f"TensorRL_fixed/LIH12q_TNbond2 (synthetic data), 2 x {half} envs x {n_steps} steps, random policy, "
+                        "half batches pipelined (step_async / step_wait)",
             "env_steps_per_s_wall": steps / dt, "env_steps_per_s_device": steps / t_gpu,
+            "device_note": "sum of the kernel times of both halves; their launches may overlap on the GPU",
             "mean_nfev_per_step": nfev / steps, "mean_rotations_at_end": float(np.mean(
-                [int((e.state[:, 12:15] == 1).sum()) for e in vec.envs]))}
+                [int((e.state[:, 12:15] == 1).sum()) for e in envs]))}
 
 
 def heis20_aux(tq, torch, dist, rank, world, dev, steps):
@@ -214,7 +235,7 @@ def main():
     ap.add_argument("--no-heis20", action="store_true")
     ap.add_argument("--episode", action="store_true", help="also run the LIH12q fixed config through "
                     "VecCircuitEnv (adds launches of the same kernel with other sizes: keep it out of profiled runs)")
-    ap.add_argument("--episode-envs", type=int, default=512)
+    ap.add_argument("--episode-envs", type=int, default=1024)
     ap.add_argument("--episode-steps", type=int, default=110)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' "

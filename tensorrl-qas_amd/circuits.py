@@ -8,14 +8,17 @@ import numpy as np
 from .engine import (Circuit, GATE_CNOT, GATE_DEPOL1, GATE_DEPOL2, GATE_RX)
 
 
-def circuit_from_state(state, n_qubits, noise=False, with_layers=False):
+def circuit_from_state(state, n_qubits, noise=False, with_layers=False, max_layer=None):
     """``state``: (L, n+6, n) tensor/array.  Per layer: CNOTs in row-major order of
     [target][control] == 1, then rotations in row-major order of [axis][qubit] == 1.
     Parameter j is the j-th rotation met, so parameters are ordered (layer, axis, qubit) -
     the same order as ``rot_pos`` in the reference's scipy_optim
     (environment_qulacs_TN_notin_agent.py:454-456).
-    Returns (Circuit, angles float64[P] read from rows n+3..n+5)."""
+    Returns (Circuit, angles float64[P] read from rows n+3..n+5).
+    ``max_layer``: optional bound on the occupied layers (an env knows it from its moments)."""
     s = state.detach().cpu().numpy() if hasattr(state, "detach") else np.asarray(state)
+    if max_layer is not None:      # caller's promise: layers >= max_layer are empty (saves the scan)
+        s = s[:max_layer]
     n = n_qubits
     kind, q0, q1, pidx, ang, lay = [], [], [], [], [], []
     cn_l, cn_t, cn_c = np.nonzero(s[:, :n, :] == 1)

@@ -264,7 +264,10 @@ class CircuitEnvBase:
             self.moments[ctrl] = self.moments[targ] = m + 1
         self.current_action = action
         self.illegal_action_new()
-        circ, ang, layers = _circ.circuit_from_state(next_state, n, noise=self.NOISY, with_layers=True)
+        # gates live in layers < offset + deepest moment: scan only those
+        self._lmax = min(int(next_state.shape[0]), off + max(self.moments) + 1)
+        circ, ang, layers = _circ.circuit_from_state(next_state, n, noise=self.NOISY, with_layers=True,
+                                                     max_layer=self._lmax)
         new_idx = -1
         for i in range(len(circ)):
             if layers[i] == key[0] and circ.kind[i] == key[1] and circ.q0[i] == key[2] and \
@@ -283,7 +286,7 @@ class CircuitEnvBase:
             rot = circ.pidx >= 0
             sel = np.nonzero(rot)[0]
             # layer / axis / qubit of every rotation, in parameter order
-            lay, ax, qb = (torch.as_tensor(v) for v in np.nonzero(next_state[:, n:n + 3, :].numpy() == 1))
+            lay, ax, qb = (torch.as_tensor(v) for v in np.nonzero(next_state[:self._lmax, n:n + 3, :].numpy() == 1))
             assert lay.numel() == sel.size
             next_state[lay, n + 3 + ax, qb] = torch.tensor(np.asarray(x_full), dtype=torch.float)
         self.opt_ang_save = x_opt

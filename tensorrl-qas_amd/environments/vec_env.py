@@ -24,6 +24,7 @@ class VecCircuitEnv:
         self.device = device
         self.num_qubits, self.num_layers = first.num_qubits, first.num_layers
         self.state_size, self.action_size = first.state_size, first.action_size
+        self._pending = None
 
     def reset(self, indices=None):
         idx = range(self.num_envs) if indices is None else indices
@@ -32,14 +33,28 @@ class VecCircuitEnv:
     def illegal_actions(self):
         return [e.illegal_action_new() for e in self.envs]
 
-    def step(self, actions, train_flag=True):
-        """``actions``: B lists [ctrl, offset, rot_qubit, rot_axis].  Returns
-        (observations (B, obs), rewards (B,), dones list[int])."""
+    def step_async(self, actions):
+        """First half of ``step``: host bookkeeping before the optimiser and the (asynchronous)
+        fused launch.  The caller may do unrelated host work - typically ``step_wait`` +
+        action selection of ANOTHER VecCircuitEnv (each has its own engine and HIP stream) -
+        before collecting the results with ``step_wait``."""
+        if self._pending is not None:
+            raise RuntimeError("step_async called twice without step_wait")
         pre = [e._pre_step(a) for e, a in zip(self.envs, actions)]
         eng = self.engine
         eng.batch_load([p[1] for p in pre], [p[2] for p in pre])
         eng.batch_set_new_gate([p[3] for p in pre])
         eng.batch_run_env_step(1.0, 1e-4, int(self.envs[0].global_iters))
+        self._pending = (pre, actions)
+
+    def step_wait(self, train_flag=True):
+        """Second half of ``step``: wait for the launch, commit angles / rewards / termination.
+        Returns (observations (B, obs), rewards (B,), dones list[int])."""
+        if self._pending is None:
+            raise RuntimeError("step_wait without step_async")
+        pre, actions = self._pending
+        self._pending = None
+        eng = self.engine
         x, f, nfev = eng.batch_fetch()
         xo = eng.batch_fetch_xopt()
         obs, rwd, done = [], [], []
@@ -53,3 +68,9 @@ class VecCircuitEnv:
         # one host-to-device copy for the whole batch
         return (torch.stack(obs).to(self.device),
                 torch.tensor(rwd, dtype=torch.float32).to(self.device), done)
+
+    def step(self, actions, train_flag=True):
+        """``actions``: B lists [ctrl, offset, rot_qubit, rot_axis].  Returns
+        (observations (B, obs), rewards (B,), dones list[int])."""
+        self.step_async(actions)
+        return self.step_wait(train_flag)
