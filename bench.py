@@ -172,7 +172,7 @@ def heis20_aux(tq, torch, dist, rank, world, dev, steps):
     """20-qubit Heisenberg <H>: every rank applies the same circuits, evaluates its share of
     the X-mask groups, one all-reduce (RCCL) sums the partial energies.  Strong scaling of
     the Pauli-term reduction."""
-    n, B, G = 20, 64, 32
+    n, B, G = 20, 256, 32      # B evaluations per all-reduce (SURVEY 8e-2: >= 64; 4 GiB of states)
     ham, _ = tq.hamiltonian.heisenberg(n)
     eng = tq.VQEEngine(n, dev)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -217,7 +217,7 @@ def heis20_aux(tq, torch, dist, rank, world, dev, steps):
     t = torch.tensor([dt, dr], dtype=torch.float64, device=f"cuda:{dev}")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return {"workload": "heisenberg_20q_77terms_G32_B64_sharded", "evals_per_s": B * steps / float(t[0].item()),
+    return {"workload": "heisenberg_20q_77terms_G32_B256_sharded", "evals_per_s": B * steps / float(t[0].item()),
             "reduction_ms_per_batch": float(t[1].item()) / steps * 1e3,
             "reduction_evals_per_s": B * steps / float(t[1].item()),
             "x_groups_total": 20, "sharding": "amplitude slices of the term sum, 1 all-reduce", "energy_checksum": float(e.sum().item()), "scaling": "strong"}
