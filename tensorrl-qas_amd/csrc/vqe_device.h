@@ -873,10 +873,17 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H, Hook
     uint32_t voff[NP / 2];
 #pragma unroll
     for (int k = 0; k < NP / 2; ++k) voff[k] = (tid + (uint32_t)k * kThreads) << 4;
+    // slots 0 .. PD-2 only: slot PD-1 is requested by the first step like every later refill, so the
+    // outstanding loads look the same on loop entry and on the back edge (the compiler's
+    // s_waitcnt bookkeeping merges both and would otherwise wait for nearly everything there)
 #pragma unroll
-    for (int j = 0; j < PD; ++j)
+    for (int j = 0; j < PD - 1; ++j) {
 #pragma unroll
       for (int k = 0; k < NP / 2; ++k) buf[j][k] = buf_load_d2(rt, voff[k], (uint32_t)j * GSTRIDE);
+      __builtin_amdgcn_sched_barrier(0);   // keep the slots in issue order
+    }
+#pragma unroll
+    for (int k = 0; k < NP / 2; ++k) buf[PD - 1][k] = make_double2(0.0, 0.0);
     double2 bA[HP], bB[HP];
     // addressing records of the group being loaded / the next one: two alternating sets
     uint2 mh[2];
