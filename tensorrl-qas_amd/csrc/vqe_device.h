@@ -65,7 +65,7 @@ struct Geo {
 };
 
 enum : int { G_CNOT = 0, G_RX = 1, G_RY = 2, G_RZ = 3, G_DEPOL1 = 4, G_DEPOL2 = 5 };
-enum : int { OP_RX = 1, OP_RY = 2, OP_RZ = 3, OP_PZ = 4 };
+enum : int { OP_RX = 1, OP_RY = 2, OP_RZ = 3, OP_PZ = 4, OP_NOP = 6 };   // (5 = OP_RELAYOUT, vqe_reg.h)
 
 struct GateRec { int32_t kind, q0, q1, pidx; };           // as uploaded by the host
 struct Op { uint32_t xm, zm; int32_t pidx; int32_t kind; };  // kind | (inv << 8)
@@ -273,8 +273,9 @@ struct Lds {
   double* red;      // [16]
   uint32_t* xm;     // [32] columns of A^-1
   uint32_t* zm;     // [32] rows of A
-  int32_t* meta;    // [8]: n_ops, offset c, phase power, permuted flag, n_sched, n_layouts
+  int32_t* meta;    // [8]: n_ops, offset c (as the final scatter wants it), phase power, permuted flag, n_sched, n_layouts, permuted by CNOTs alone, raw offset c
   uint32_t* sb;     // [16] scheduler scratch
+  uint16_t* sidx;   // [max_ops] position of raw op k in the executed list (sched for n >= 10, ops below)
 };
 
 // n >= 10: the raw ops only live while the schedule is built, in the (idle) state region.
@@ -283,7 +284,7 @@ __host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params, 
   size_t b = (size_t)16 << n;
   b += n >= 10 ? (size_t)16 * (2 * max_ops + 2) + (size_t)32 * (max_ops + 2) : (size_t)16 * max_ops;
   b += (size_t)16 * max_params + (size_t)16 * ng + (n >= 10 ? (size_t)48 * ng : 0);
-  return b + 128 + 128 + 128 + 32 + 64;
+  return b + 128 + 128 + 128 + 32 + 64 + (((size_t)2 * max_ops + 15) & ~(size_t)15);
 }
 
 __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, int max_params, int n_groups) {
@@ -305,7 +306,8 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, in
   l.xm = (uint32_t*)base; base += 128;
   l.zm = (uint32_t*)base; base += 128;
   l.meta = (int32_t*)base; base += 32;
-  l.sb = (uint32_t*)base;
+  l.sb = (uint32_t*)base; base += 64;
+  l.sidx = (uint16_t*)base;
   return l;
 }
 
@@ -338,7 +340,12 @@ __device__ __forceinline__ void stage_cls(const HamDev& H, const Lds& L) {
 // Translate the gate list of problem b into pair-exchange ops (CNOT / Pauli-X become
 // updates of the affine map).  All threads stage the gate records into the (idle) state
 // region, thread 0 walks them.  Noise Paulis are drawn per evaluation.  Ends with a barrier.
-__device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip = -1) {
+// `slots`: structure-only compile for stochastic runs.  Every noise gate leaves one inactive
+// Pauli-Z slot per qubit it acts on (kind OP_NOP) and draws nothing; patch_noise() then sets,
+// for each evaluation, which slots are active and the sign bits that X errors flip - the
+// masks, the layouts and the schedule do not depend on the errors drawn.
+__device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip = -1,
+                                            bool slots = false) {
   const int n = A.n;
   const int G = A.gate_count[b];
   const int cap = (int)(((size_t)16 << n) / sizeof(GateRec)) / (n >= 10 ? 2 : 1);
@@ -346,9 +353,21 @@ __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t 
   GateRec* gl = (GateRec*)L.psi;
   const bool staged = G <= cap;
   if (staged) {
+    // every thread stages its records and - for noise gates - draws the Pauli error now, in
+    // parallel (code 0..15 in the unused pidx field): the serial walk below then hashes nothing
     const int4* s4 = (const int4*)gsrc;
     int4* d4 = (int4*)gl;
-    for (int i = threadIdx.x; i < G; i += (int)blockDim.x) d4[i] = s4[i];
+    for (int i = threadIdx.x; i < G; i += (int)blockDim.x) {
+      int4 r = s4[i];
+      if (r.x == G_DEPOL1 || r.x == G_DEPOL2) {
+        const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
+        int code = 0;
+        if (r.x == G_DEPOL1) { if (u < A.noise.p1) code = 1 + (int)(u / A.noise.p1 * 3.0); }
+        else if (u < A.noise.p2) code = 1 + (int)(u / A.noise.p2 * 15.0);
+        r.w = code;
+      }
+      d4[i] = r;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -367,9 +386,18 @@ __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t 
       }
       if (p == 2) phase = (phase + 3) & 3;
     };
+    auto slot = [&](int q) {
+      if (nops < A.max_ops) L.ops[nops] = Op{0u, zm[q], -1, OP_NOP};
+      ++nops;
+    };
     for (int i = 0; i < G; ++i) {
       if (i == skip) continue;
       const GateRec r = g[i];
+      if (slots && (r.kind == G_DEPOL1 || r.kind == G_DEPOL2)) {
+        slot(r.q0);
+        if (r.kind == G_DEPOL2) slot(r.q1);
+        continue;
+      }
       switch (r.kind) {
         case G_CNOT:
           zm[r.q1] ^= zm[r.q0];
@@ -382,14 +410,19 @@ __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t 
           ++nops;
           break;
         case G_DEPOL1: {
+          if (staged) { pauli(r.q0, r.pidx); break; }
           const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
           if (u < A.noise.p1) pauli(r.q0, 1 + (int)(u / A.noise.p1 * 3.0));
           break;
         }
         case G_DEPOL2: {
-          const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
-          if (u < A.noise.p2) {
-            const int idx = 1 + (int)(u / A.noise.p2 * 15.0);
+          int idx = 0;
+          if (staged) idx = r.pidx;
+          else {
+            const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
+            if (u < A.noise.p2) idx = 1 + (int)(u / A.noise.p2 * 15.0);
+          }
+          if (idx) {
             pauli(r.q0, idx & 3);
             pauli(r.q1, idx >> 2);
           }
@@ -404,6 +437,91 @@ __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t 
     L.meta[1] = (int32_t)c;
     L.meta[2] = phase;
     L.meta[3] = permuted;
+    L.meta[6] = permuted;
+    L.meta[7] = (int32_t)c;
+  }
+  __syncthreads();
+}
+
+// Per-evaluation part of a stochastic run (after a `slots` compile): draw the Pauli errors of
+// this (stream, evaluation) in parallel, then one thread walks the gate list tracking only the
+// offset c and patches the executed records in place: sign bit of every rotation, activity and
+// sign bit of every Pauli-Z slot.  `canonical`: the final scatter wants M c (see compile_all).
+template <int N>
+__device__ __forceinline__ void patch_noise(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip,
+                                            bool canonical) {
+  // One wave.  Lane l holds gate base+l and draws its Pauli error; everything that does not depend
+  // on the running offset c (record numbers by a wave prefix sum, Z activity, the masks each gate
+  // XORs into c) is prepared per lane, so the serial walk is a short branch-free scalar loop that
+  // reads two packed words per gate with v_readlane and collects the sign bits in 64-bit masks.
+  const int G = A.gate_count[b];
+  const int4* gsrc = (const int4*)(A.gates + A.gate_begin[b]);
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    Op* exe = N >= 10 ? L.sched : L.ops;
+    const int kmax = L.meta[0];
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t c = 0;
+    int ny = 0, kbase = 0;
+    for (int base = 0; base < G; base += 64) {
+      const int i = base + lane;
+      int kind = -1, q0 = 0, q1 = 0, code = 0;
+      if (i < G && i != skip) {
+        const int4 r = gsrc[i];
+        kind = r.x; q0 = r.y; q1 = r.z < 0 ? 0 : r.z;
+        if (kind == G_DEPOL1 || kind == G_DEPOL2) {
+          const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
+          if (kind == G_DEPOL1) { if (u < A.noise.p1) code = 1 + (int)(u / A.noise.p1 * 3.0); }
+          else if (u < A.noise.p2) code = 1 + (int)(u / A.noise.p2 * 15.0);
+        }
+      }
+      // Pauli on q0 / q1: 1=X 2=Y 3=Z (compile_ops' rule: X part first, then the Z slot reads c)
+      const int pa = kind == G_DEPOL1 ? code : (kind == G_DEPOL2 ? (code & 3) : 0);
+      const int pb = kind == G_DEPOL2 ? (code >> 2) : 0;
+      const uint32_t flip_a = (pa == 1 || pa == 2) ? 1u << q0 : 0u;
+      const uint32_t flip_b = (pb == 1 || pb == 2) ? 1u << q1 : 0u;
+      const uint32_t cnot_m = kind == G_CNOT ? 1u << q1 : 0u;
+      const int nrec = (kind >= G_RX && kind <= G_DEPOL1) ? 1 : (kind == G_DEPOL2 ? 2 : 0);
+      const uint32_t w1 = flip_a | ((uint32_t)q0 << 16) | ((uint32_t)q1 << 24);
+      const uint32_t w2 = cnot_m | (flip_b << 16);
+      const uint64_t has1 = __ballot(nrec >= 1), has2 = __ballot(nrec == 2);
+      const int k0 = kbase + __popcll(has1 & lt_mask) + __popcll(has2 & lt_mask);
+      kbase += __popcll(has1) + __popcll(has2);
+      ny += __popcll(__ballot(pa == 2)) + __popcll(__ballot(pb == 2));
+      uint64_t inv0 = 0, inv1 = 0;
+      const int cnt = G - base < 64 ? G - base : 64;
+      for (int j = 0; j < cnt; ++j) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)w1, j);
+        const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)w2, j);
+        c ^= a & 0xffffu;                                   // X error on q0
+        const uint32_t b0 = (c >> ((a >> 16) & 31u)) & 1u;  // sign bit of record 0 / CNOT control
+        c ^= (0u - b0) & (bw & 0xffffu);                    // CNOT: target follows the control
+        inv0 |= (uint64_t)b0 << j;
+        c ^= bw >> 16;                                      // X error on q1
+        inv1 |= (uint64_t)((c >> (a >> 24)) & 1u) << j;     // sign bit of record 1
+      }
+      auto apply = [&](int pk, int sign, int pauli) {   // pauli < 0: a rotation, kind stays
+        if (pk < kmax) {
+          Op* o = exe + L.sidx[pk];
+          int kd = o->kind;
+          if (pauli >= 0) kd = (kd & ~0xff) | ((pauli == 2 || pauli == 3) ? OP_PZ : OP_NOP);
+          o->kind = (kd & ~0x100) | (sign << 8);
+        }
+      };
+      if (nrec >= 1) apply(k0, (int)((inv0 >> lane) & 1ull), kind <= G_RZ ? -1 : pa);
+      if (nrec == 2) apply(k0 + 1, (int)((inv1 >> lane) & 1ull), pb);
+    }
+    if (lane == 0) {
+      uint32_t cs = c;
+      if (N >= 10 && canonical) {
+        cs = 0;
+        for (int q = 0; q < N; ++q) cs |= (uint32_t)parity32(A.ham.mrow[q] & c) << q;
+      }
+      L.meta[1] = (int32_t)cs;
+      L.meta[2] = (3 * ny) & 3;
+      L.meta[3] = L.meta[6] | (c != 0);
+      L.meta[7] = (int32_t)c;
+    }
   }
   __syncthreads();
 }
@@ -415,8 +533,14 @@ namespace vqe {
 // compile + (n >= 10) schedule for the register-resident path; ends with a barrier
 template <int N>
 __device__ __forceinline__ void compile_all(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip = -1,
-                                            bool canonical = true) {
-  compile_ops(A, b, eval_id, L, skip);
+                                            bool canonical = true, bool slots = false) {
+  compile_ops(A, b, eval_id, L, skip, slots);
+  if constexpr (N < 10) {   // (kRegMinQubits)
+    if (slots) {
+      for (int k = threadIdx.x; k < L.meta[0]; k += (int)blockDim.x) L.sidx[k] = (uint16_t)k;
+      __syncthreads();
+    }
+  }
   if constexpr (N >= kRegMinQubits) {
     if (threadIdx.x == 0) schedule_ops<N>(L);
     __syncthreads();
@@ -501,7 +625,7 @@ __device__ __forceinline__ void run_ops(const Lds& L, const double* theta, int P
           L.psi[p] = make_double2(cs.x * a.x - s * a.y, cs.x * a.y + s * a.x);
         }
       }
-    } else {  // OP_PZ
+    } else if (kind == OP_PZ) {   // (OP_NOP: an inactive noise slot)
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
         const uint32_t p = tid + k * kThreads;
@@ -1103,7 +1227,8 @@ __global__ void __launch_bounds__(Geo<N>::NT) k_lds_energy(BatchArgs A) {
   const bool noisy = (A.noise.p1 > 0.0 || A.noise.p2 > 0.0);
   stage_groups(A.ham, L);
   if constexpr (N >= 10) stage_cls<N>(A.ham, L);
-  compile_all<N>(A, b, noisy ? A.noise.eval_base : 0, L);
+  compile_all<N>(A, b, 0, L, -1, true, noisy);
+  if (noisy) patch_noise<N>(A, b, A.noise.eval_base, L, -1, true);
   double e = lds_evaluate<N>(A, L, A.theta + A.par_begin[b], A.par_count[b]);
   if (A.noise.shot_sigma != 0.0) e += A.noise.shot_sigma * noise_gauss(A.noise.seed, (uint64_t)b, A.noise.eval_base);
   if (threadIdx.x == 0) { A.fout[b] = e; if (A.nfev) A.nfev[b] = 1; }
@@ -1114,7 +1239,9 @@ __global__ void __launch_bounds__(Geo<N>::NT) k_lds_state(BatchArgs A) {
   constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
-  compile_all<N>(A, 0, A.noise.eval_base, L, -1, false);   // logical order for the read-out
+  const bool noisy_state = (A.noise.p1 > 0.0 || A.noise.p2 > 0.0);
+  compile_all<N>(A, 0, 0, L, -1, false, noisy_state);   // logical order for the read-out
+  if (noisy_state) patch_noise<N>(A, 0, A.noise.eval_base, L, -1, false);
   if constexpr (N >= kRegMinQubits) {
     run_ops_reg<N>(L, A.init, A.theta + A.par_begin[0], A.par_count[0]);
   } else {
@@ -1179,7 +1306,8 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
     const int ph = phase == 2 ? -1 : p_hole;
     const uint64_t eid = A.noise.eval_base +
                          (phase == 1 ? (uint64_t)sc.nfvals : (phase == 2 ? (uint64_t)A.maxfun + 1 : 0));
-    if (noisy || need_compile) { compile_all<N>(A, b, noisy ? eid : 0, L, sk); need_compile = false; }
+    if (need_compile) { compile_all<N>(A, b, 0, L, sk, true, noisy); need_compile = false; }
+    if (noisy) patch_noise<N>(A, b, eid, L, sk, true);
     double e = lds_evaluate<N>(A, L, th, P, ph);
     // finite-shot estimate of <H>: Gaussian with the total standard deviation the caller set
     if (A.noise.shot_sigma != 0.0) e += A.noise.shot_sigma * noise_gauss(A.noise.seed, (uint64_t)b, eid);

@@ -117,6 +117,7 @@ __device__ __forceinline__ void schedule_ops(const Lds& L) {
     }
     uint32_t svec = 0;
     for (int i = 0; i < R; ++i) svec |= (uint32_t)parity32(op.zm & B.e[i]) << i;
+    L.sidx[o] = (uint16_t)ns;
     L.sched[ns++] = Op{sign_word<R>(svec), op.zm, op.pidx >= 0 ? op.pidx * 16 : 0, op.kind | (int32_t)(j << 16)};
   }
   L.sched[ns] = Op{0u, 0u, 0, 0};   // the run loop prefetches one record past the end
@@ -286,6 +287,7 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
 #endif
       continue;
     }
+    if (kind == OP_NOP) continue;   // inactive noise slot
     const int inv = (op.kind >> 8) & 1;
     const uint32_t flip = (uint32_t)(parity32(op.zm & base) ^ inv);
     const uint32_t w = op.xm ^ (0u - flip);
@@ -298,7 +300,7 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
 #pragma unroll
       for (int r = 0; r < NA; r += 2)
         rot2x2(amp[r].x, amp[r].y, amp[r + 1].x, amp[r + 1].y, cs.x, flip_if(cs.y, w, r), flip_if(cs.y, w, r + 1));
-    } else {  // OP_PZ
+    } else if (kind == OP_PZ) {   // (OP_NOP: an inactive noise slot)
 #pragma unroll
       for (int r = 0; r < NA; ++r) amp[r] = make_double2(flip_if(amp[r].x, w, r), flip_if(amp[r].y, w, r));
     }
