@@ -131,11 +131,17 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 // Uniform [0,1) draw for (stream b, evaluation e, gate g): a pure function of the seed.
-__device__ __forceinline__ double noise_uniform(uint64_t seed, uint64_t b, uint64_t e, uint64_t g) {
-  uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ull * (b + 1));
-  k = mix64(k ^ (e * 0xBF58476D1CE4E5B9ull));
-  k = mix64(k ^ (g * 0x94D049BB133111EBull));
+// noise_key() is the part that does not depend on the gate (hoisted out of per-gate loops).
+__device__ __forceinline__ uint64_t noise_key(uint64_t seed, uint64_t b, uint64_t e) {
+  const uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ull * (b + 1));
+  return mix64(k ^ (e * 0xBF58476D1CE4E5B9ull));
+}
+__device__ __forceinline__ double noise_uniform_k(uint64_t key, uint64_t g) {
+  const uint64_t k = mix64(key ^ (g * 0x94D049BB133111EBull));
   return (double)(k >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double noise_uniform(uint64_t seed, uint64_t b, uint64_t e, uint64_t g) {
+  return noise_uniform_k(noise_key(seed, b, e), g);
 }
 
 // Standard normal draw for (stream b, evaluation e): Box-Muller on two draws of the same
@@ -344,7 +350,7 @@ __device__ __forceinline__ void stage_cls(const HamDev& H, const Lds& L) {
 // Pauli-Z slot per qubit it acts on (kind OP_NOP) and draws nothing; patch_noise() then sets,
 // for each evaluation, which slots are active and the sign bits that X errors flip - the
 // masks, the layouts and the schedule do not depend on the errors drawn.
-__device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip = -1,
+__device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t /*eval_id*/, const Lds& L, int skip = -1,
                                             bool slots = false) {
   const int n = A.n;
   const int G = A.gate_count[b];
@@ -353,21 +359,9 @@ __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t 
   GateRec* gl = (GateRec*)L.psi;
   const bool staged = G <= cap;
   if (staged) {
-    // every thread stages its records and - for noise gates - draws the Pauli error now, in
-    // parallel (code 0..15 in the unused pidx field): the serial walk below then hashes nothing
     const int4* s4 = (const int4*)gsrc;
     int4* d4 = (int4*)gl;
-    for (int i = threadIdx.x; i < G; i += (int)blockDim.x) {
-      int4 r = s4[i];
-      if (r.x == G_DEPOL1 || r.x == G_DEPOL2) {
-        const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
-        int code = 0;
-        if (r.x == G_DEPOL1) { if (u < A.noise.p1) code = 1 + (int)(u / A.noise.p1 * 3.0); }
-        else if (u < A.noise.p2) code = 1 + (int)(u / A.noise.p2 * 15.0);
-        r.w = code;
-      }
-      d4[i] = r;
-    }
+    for (int i = threadIdx.x; i < G; i += (int)blockDim.x) d4[i] = s4[i];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -377,15 +371,6 @@ __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t 
     for (int q = 0; q < n; ++q) { xm[q] = 1u << q; zm[q] = 1u << q; }
     uint32_t c = 0;
     int phase = 0, nops = 0;
-    auto pauli = [&](int q, int p) {  // 1=X 2=Y 3=Z on logical qubit q
-      if (p == 0) return;
-      if (p == 1 || p == 2) c ^= 1u << q;
-      if (p == 2 || p == 3) {
-        if (nops < A.max_ops) L.ops[nops] = Op{0u, zm[q], -1, OP_PZ | (int)(((c >> q) & 1u) << 8)};
-        ++nops;
-      }
-      if (p == 2) phase = (phase + 3) & 3;
-    };
     auto slot = [&](int q) {
       if (nops < A.max_ops) L.ops[nops] = Op{0u, zm[q], -1, OP_NOP};
       ++nops;
@@ -409,25 +394,7 @@ __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t 
             L.ops[nops] = Op{xm[r.q0], zm[r.q0], r.pidx, r.kind | (int)(((c >> r.q0) & 1u) << 8)};
           ++nops;
           break;
-        case G_DEPOL1: {
-          if (staged) { pauli(r.q0, r.pidx); break; }
-          const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
-          if (u < A.noise.p1) pauli(r.q0, 1 + (int)(u / A.noise.p1 * 3.0));
-          break;
-        }
-        case G_DEPOL2: {
-          int idx = 0;
-          if (staged) idx = r.pidx;
-          else {
-            const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
-            if (u < A.noise.p2) idx = 1 + (int)(u / A.noise.p2 * 15.0);
-          }
-          if (idx) {
-            pauli(r.q0, idx & 3);
-            pauli(r.q1, idx >> 2);
-          }
-          break;
-        }
+        // (noise gates: slots above, or ignored - the errors are applied by patch_noise)
         default: break;
       }
     }
@@ -461,6 +428,7 @@ __device__ __forceinline__ void patch_noise(const BatchArgs& A, int b, uint64_t 
     Op* exe = N >= 10 ? L.sched : L.ops;
     const int kmax = L.meta[0];
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const uint64_t nkey = noise_key(A.noise.seed, (uint64_t)b, eval_id);
     uint32_t c = 0;
     int ny = 0, kbase = 0;
     for (int base = 0; base < G; base += 64) {
@@ -470,7 +438,7 @@ __device__ __forceinline__ void patch_noise(const BatchArgs& A, int b, uint64_t 
         const int4 r = gsrc[i];
         kind = r.x; q0 = r.y; q1 = r.z < 0 ? 0 : r.z;
         if (kind == G_DEPOL1 || kind == G_DEPOL2) {
-          const double u = noise_uniform(A.noise.seed, (uint64_t)b, eval_id, (uint64_t)i);
+          const double u = noise_uniform_k(nkey, (uint64_t)i);
           if (kind == G_DEPOL1) { if (u < A.noise.p1) code = 1 + (int)(u / A.noise.p1 * 3.0); }
           else if (u < A.noise.p2) code = 1 + (int)(u / A.noise.p2 * 15.0);
         }
@@ -586,6 +554,7 @@ __device__ __forceinline__ void run_ops(const Lds& L, const double* theta, int P
   for (int o = 0; o < nops; ++o) {
     const Op op = L.ops[o];
     const int kind = op.kind & 0xff;
+    if (kind == OP_NOP) continue;   // inactive noise slot: nothing to do, no barrier needed
     const int inv = (op.kind >> 8) & 1;
     if (kind == OP_RX || kind == OP_RY) {
       const double2 cs = L.cs[op.pidx];
