@@ -199,3 +199,36 @@ def test_restricted_shot_noise_env(data_root):
     es = np.array([noisy.get_energy()[0] for _ in range(200)])
     sig = np.linalg.norm(case["weights"]) / 100.0
     assert abs(es.mean() - gold) < 5 * sig / np.sqrt(es.size) and 0.7 * sig < es.std() < 1.3 * sig
+
+
+def test_vec_env_async_halves_equal_plain_steps(data_root):
+    """step_async / step_wait of two VecCircuitEnv halves interleaved (the software pipeline of
+    bench.py's episode loop) give exactly the results of plain step() calls."""
+    from tensorrl_qas_amd.environments.environment_qulacs_TN_notin_agent import CircuitEnv
+    from tensorrl_qas_amd.environments.vec_env import VecCircuitEnv
+    from tensorrl_qas_amd.environments.utils.utils import dictionary_of_actions
+    conf = reference_config("TensorRL_fixed/BEH26q_TNbond2", data_root)
+    conf["non_local_opt"]["global_iters"] = 100
+    dev = torch.device("cuda:0")
+    B = 4
+    table = dictionary_of_actions(6)
+    rng = np.random.default_rng(3)
+    scripts = [[[int(a) for a in rng.integers(0, len(table), 3)] for _ in range(B)] for _ in range(2)]
+    halves = [VecCircuitEnv(CircuitEnv, conf, dev, B) for _ in range(2)]
+    plain = [VecCircuitEnv(CircuitEnv, conf, dev, B) for _ in range(2)]
+    for v in halves + plain:
+        v.reset()
+    with pytest.raises(RuntimeError):
+        halves[0].step_wait()
+    out = [[], []]
+    halves[0].step_async([table[s[0]] for s in scripts[0]])
+    for t in range(3):
+        halves[1].step_async([table[s[t]] for s in scripts[1]])
+        out[0].append(halves[0].step_wait())
+        if t + 1 < 3:
+            halves[0].step_async([table[s[t + 1]] for s in scripts[0]])
+        out[1].append(halves[1].step_wait())
+    for h in range(2):
+        for t in range(3):
+            o, r, d = plain[h].step([table[s[t]] for s in scripts[h]])
+            assert torch.equal(o, out[h][t][0]) and torch.equal(r, out[h][t][1]) and d == out[h][t][2]

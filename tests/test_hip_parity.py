@@ -471,3 +471,46 @@ def test_shot_noise_matches_restated_generator(tq):
     assert abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.std() - 1) < 0.05
     eng.set_shot_noise(0.0, seed)
     assert abs(eng.energy(th) - clean) < 1e-13
+
+
+def test_bench_workload_parity(tq):
+    """The bench workload itself at full size (12 qubits, the synthetic 631-term LiH-like
+    Hamiltonian with 91 X-mask groups, 64-gate random circuits): every energy of a slice of
+    the batch against the oracle, the fused env-step's reported energy against the oracle at
+    the returned (float32-rounded) parameters, and linearity of <H> in the Pauli weights."""
+    import bench
+    n, G, B = 12, 64, 24
+    H = tq.hamiltonian.synthetic_lih12()
+    psi0 = tq.hamiltonian.brickwork_state(n, 12)
+    ham = (H.xmask, H.zmask, H.coeff)
+    eng = _engine(tq, n, psi0, ham)
+    b = bench.make_batch(tq, n, B, G, 1000)
+    eng.batch_load_flat(b["gate_off"], b["kind"], b["q0"], b["q1"], b["pidx"], b["par_off"], b["theta"])
+    eng.batch_run_energy()
+    _, f, _ = eng.batch_fetch()
+    kind = b["kind"].reshape(B, G); q0 = b["q0"].reshape(B, G); q1 = b["q1"].reshape(B, G); pidx = b["pidx"].reshape(B, G)
+    refs = []
+    for i in range(B):
+        th = b["theta"][b["par_off"][i]:b["par_off"][i + 1]]
+        psi = vo.run_circuit(psi0, kind[i], q0[i], q1[i], pidx[i], th)
+        refs.append(vo.energy_pauli(psi, *ham))
+        assert abs(f[i] - refs[-1]) < E_TOL
+    # linearity: H = H_a + H_b (split of the terms) -> energies add
+    half = len(H.coeff) // 2
+    tot = np.zeros(B)
+    for sl in (slice(0, half), slice(half, None)):
+        e2 = _engine(tq, n, psi0, (H.xmask[sl], H.zmask[sl], H.coeff[sl]))
+        e2.batch_load_flat(b["gate_off"], b["kind"], b["q0"], b["q1"], b["pidx"], b["par_off"], b["theta"])
+        e2.batch_run_energy()
+        tot += e2.batch_fetch()[1]
+    assert np.abs(tot - f).max() < E_TOL
+    # fused env-step (COBYLA without the new gate, float32 round trip, post-action energy)
+    eng.batch_set_new_gate(b["new_gate"])
+    eng.batch_run_env_step(1.0, 1e-4, 150)
+    x, fe, nfev = eng.batch_fetch()
+    for i in range(B):
+        xi = x[b["par_off"][i]:b["par_off"][i + 1]]
+        assert np.array_equal(xi, xi.astype(np.float32).astype(np.float64))
+        psi = vo.run_circuit(psi0, kind[i], q0[i], q1[i], pidx[i], xi)
+        assert abs(vo.energy_pauli(psi, *ham) - fe[i]) < E_TOL
+        assert 1 <= nfev[i] <= 150
