@@ -64,6 +64,11 @@ struct Geo {
   static constexpr int WPS = N <= 11 ? 4 : 2;      // waves per SIMD asked of the register allocator
 };
 
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const unsigned char lds_cbyte;
+
 enum : int { G_CNOT = 0, G_RX = 1, G_RY = 2, G_RZ = 3, G_DEPOL1 = 4, G_DEPOL2 = 5 };
 enum : int { OP_RX = 1, OP_RY = 2, OP_RZ = 3, OP_PZ = 4, OP_NOP = 6 };   // (5 = OP_RELAYOUT, vqe_reg.h)
 
@@ -862,10 +867,6 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
 // belongs to r = insert0(j, cls).  Same software pipeline as energy_real_lds (half groups,
 // PD-deep table ring, X mask fetched one step ahead); the class dispatch is a wave-uniform
 // switch around the arithmetic only.
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-typedef int v2i_t __attribute__((ext_vector_type(2)));
-typedef double d2v_t __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) const unsigned char lds_cbyte;
 
 // Table reads through a buffer descriptor: one instruction per load (SGPR descriptor + SGPR
 // group offset + loop-invariant VGPR lane offset), no 64-bit address arithmetic per group.

@@ -240,16 +240,28 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
     L.cs[j] = make_double2(c, s);
   }
   double2 amp[NA];
+  // layout vectors and the thread's base index are kept as BYTE offsets (<< 4): one XOR per
+  // LDS address instead of XOR + shift
   uint32_t e[5];
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  lds_byte* psi_l = (lds_byte*)L.psi;
+  auto lds_get = [&](uint32_t off) {
+    const d2v_t v = *(const __attribute__((address_space(3))) d2v_t*)(psi_l + off);
+    return make_double2(v.x, v.y);
+  };
+  auto lds_put = [&](uint32_t off, const double2& a) {
+    d2v_t v; v.x = a.x; v.y = a.y;
+    *(__attribute__((address_space(3))) d2v_t*)(psi_l + off) = v;
+  };
+  uint32_t base = deposit<LT>(tid, L.lay[0].pos, L.lay[0].pos8);
   {
     const LayoutRec lr = L.lay[0];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) e[i] = lr.e[i];
-    const uint32_t base0 = deposit<LT>(tid, lr.pos, lr.pos8);
+    for (int i = 0; i < 5; ++i) e[i] = lr.e[i] << 4;
+    const unsigned char* init_b = (const unsigned char*)init;
 #pragma unroll
-    for (int r = 0; r < NA; ++r) amp[r] = init[base0 ^ combo<R>(e, r)];
+    for (int r = 0; r < NA; ++r) amp[r] = *(const double2*)(init_b + ((base << 4) ^ combo<R>(e, r)));
   }
-  uint32_t base = deposit<LT>(tid, L.lay[0].pos, L.lay[0].pos8);
   // all initial amplitudes in: otherwise every case of the gate switch carries its own waits
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __syncthreads();   // cs[] visible
@@ -273,15 +285,21 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
       const long long tr0 = clock64();
 #endif
       __syncthreads();                                   // earlier reads of psi are done
+      {
+        const uint32_t b16 = base << 4;
 #pragma unroll
-      for (int r = 0; r < NA; ++r) L.psi[base ^ combo<R>(e, r)] = amp[r];
+        for (int r = 0; r < NA; ++r) lds_put(b16 ^ combo<R>(e, r), amp[r]);
+      }
       const LayoutRec lr = L.lay[op.xm];
 #pragma unroll
-      for (int i = 0; i < 5; ++i) e[i] = lr.e[i];
+      for (int i = 0; i < 5; ++i) e[i] = lr.e[i] << 4;
       base = deposit<LT>(tid, lr.pos, lr.pos8);
       __syncthreads();
+      {
+        const uint32_t b16 = base << 4;
 #pragma unroll
-      for (int r = 0; r < NA; ++r) amp[r] = L.psi[base ^ combo<R>(e, r)];
+        for (int r = 0; r < NA; ++r) amp[r] = lds_get(b16 ^ combo<R>(e, r));
+      }
 #ifdef VQE_STAMPS
       trel += clock64() - tr0;
 #endif
@@ -309,18 +327,18 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
   const long long ts2 = clock64();
 #endif
   // scatter to logical order: i = A * p ^ c, bit q of A*p = parity(zm[q] & p)
-  uint32_t ib = (uint32_t)L.meta[1];
+  uint32_t ib = (uint32_t)L.meta[1] << 4;            // byte offsets again
   uint32_t ae[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
   for (int q = 0; q < N; ++q) {
     const uint32_t z = L.zm[q];
-    ib ^= (uint32_t)parity32(z & base) << q;
+    ib ^= (uint32_t)parity32(z & base) << (q + 4);
 #pragma unroll
-    for (int i = 0; i < R; ++i) ae[i] |= (uint32_t)parity32(z & e[i]) << q;
+    for (int i = 0; i < R; ++i) ae[i] |= (uint32_t)parity32(z & (e[i] >> 4)) << (q + 4);
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < NA; ++r) L.psi[ib ^ combo<R>(ae, r)] = amp[r];
+  for (int r = 0; r < NA; ++r) lds_put(ib ^ combo<R>(ae, r), amp[r]);
   __syncthreads();
 #ifdef VQE_STAMPS
   if (threadIdx.x == 0 && dbg) {
