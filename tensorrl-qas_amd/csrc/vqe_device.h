@@ -420,16 +420,15 @@ __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t 
 // offset c and patches the executed records in place: sign bit of every rotation, activity and
 // sign bit of every Pauli-Z slot.  `canonical`: the final scatter wants M c (see compile_all).
 template <int N>
-__device__ __forceinline__ void patch_noise(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip,
-                                            bool canonical) {
+__device__ __forceinline__ void patch_noise_wave(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip,
+                                                 bool canonical, int lane) {
   // One wave.  Lane l holds gate base+l and draws its Pauli error; everything that does not depend
   // on the running offset c (record numbers by a wave prefix sum, Z activity, the masks each gate
   // XORs into c) is prepared per lane, so the serial walk is a short branch-free scalar loop that
   // reads two packed words per gate with v_readlane and collects the sign bits in 64-bit masks.
   const int G = A.gate_count[b];
   const int4* gsrc = (const int4*)(A.gates + A.gate_begin[b]);
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
+  {
     Op* exe = N >= 10 ? L.sched : L.ops;
     const int kmax = L.meta[0];
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -496,6 +495,13 @@ __device__ __forceinline__ void patch_noise(const BatchArgs& A, int b, uint64_t 
       L.meta[7] = (int32_t)c;
     }
   }
+}
+
+// ... by wave 0 of the workgroup, followed by a barrier.
+template <int N>
+__device__ __forceinline__ void patch_noise(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip,
+                                            bool canonical) {
+  if (threadIdx.x < 64) patch_noise_wave<N>(A, b, eval_id, L, skip, canonical, (int)threadIdx.x);
   __syncthreads();
 }
 
@@ -1094,6 +1100,7 @@ __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L,
 // COBYLA with its matrices staged into the state region of LDS while the state is dead
 // (between two evaluations); falls back to the global scratch when they do not fit.
 typedef __attribute__((address_space(3))) double lds_double;
+struct NoSide { __device__ __forceinline__ void operator()() const {} };
 
 template <int N>
 struct StagedCobyla {
@@ -1149,8 +1156,10 @@ struct StagedCobyla {
     nfvals = cob.nfvals;
     cob.save_state();
   }
-  template <bool FIRST>
-  __device__ __forceinline__ int run(double f, double rhobeg, double rhoend, int maxfun) {
+  // `side()` runs on the second wave while the first one does the optimiser's bookkeeping (the
+  // env-step kernel prepares the noise patches of the next evaluation there)
+  template <bool FIRST, class Side>
+  __device__ __forceinline__ int run(double f, double rhobeg, double rhoend, int maxfun, Side side) {
 #ifdef VQE_STAMPS
     const long long t0 = clock64();
 #endif
@@ -1161,6 +1170,8 @@ struct StagedCobyla {
     if (threadIdx.x < 64) {
       if (staged) call<FIRST, CobL>((lds_double*)lmem, f, rhobeg, rhoend, maxfun);
       else call<FIRST, CobG>(gmem, f, rhobeg, rhoend, maxfun);
+    } else if (threadIdx.x < 128) {
+      side();
     }
 #ifdef VQE_STAMPS
     const long long t2 = clock64();
@@ -1175,12 +1186,13 @@ struct StagedCobyla {
 #endif
     return want;
   }
-  __device__ __forceinline__ int start(double rhobeg, double rhoend, int maxfun) { return run<true>(0.0, rhobeg, rhoend, maxfun); }
-  __device__ __forceinline__ int tell(double f, unsigned long long* __restrict__ dbg = nullptr) {
+  __device__ __forceinline__ int start(double rhobeg, double rhoend, int maxfun) { return run<true>(0.0, rhobeg, rhoend, maxfun, NoSide()); }
+  template <class Side>
+  __device__ __forceinline__ int tell(double f, unsigned long long* __restrict__ dbg, Side side) {
 #ifdef VQE_STAMPS
     const long long t0 = clock64();
 #endif
-    const int w = run<false>(f, 0.0, 0.0, 0);
+    const int w = run<false>(f, 0.0, 0.0, 0, side);
 #ifdef VQE_STAMPS
     if (threadIdx.x == 0) atomicAdd(dbg + 4, (unsigned long long)(clock64() - t0));
 #endif
@@ -1261,6 +1273,7 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
   // 2 = post-action evaluation of env_step.  ONE evaluation call site keeps everything inlined.
   int phase = 0, nfev = 1;
   bool need_compile = true;
+  bool patched = false;   // the noise patches of the coming evaluation are already in (made during tell())
   double fret = 0.0, flast = 0.0;
   if (Popt > 0) {
     sc.init(A.scratch + A.scratch_begin[b], L, Popt);
@@ -1276,8 +1289,9 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
     const int ph = phase == 2 ? -1 : p_hole;
     const uint64_t eid = A.noise.eval_base +
                          (phase == 1 ? (uint64_t)sc.nfvals : (phase == 2 ? (uint64_t)A.maxfun + 1 : 0));
-    if (need_compile) { compile_all<N>(A, b, 0, L, sk, true, noisy); need_compile = false; }
-    if (noisy) patch_noise<N>(A, b, eid, L, sk, true);
+    if (need_compile) { compile_all<N>(A, b, 0, L, sk, true, noisy); need_compile = false; patched = false; }
+    if (noisy && !patched) patch_noise<N>(A, b, eid, L, sk, true);
+    patched = false;
     double e = lds_evaluate<N>(A, L, th, P, ph);
     // finite-shot estimate of <H>: Gaussian with the total standard deviation the caller set
     if (A.noise.shot_sigma != 0.0) e += A.noise.shot_sigma * noise_gauss(A.noise.seed, (uint64_t)b, eid);
@@ -1294,7 +1308,12 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
 #ifdef VQE_STAMPS
       const long long tt0 = clock64();
 #endif
-      const int want = sc.tell(e, A.dbg);
+      // while wave 0 updates the simplex, wave 1 draws and applies the errors of the next evaluation
+      const uint64_t eid_next = A.noise.eval_base + (uint64_t)sc.nfvals + 1;
+      const int want = sc.tell(e, A.dbg, [&]() {
+        if (noisy) patch_noise_wave<N>(A, b, eid_next, L, sk, true, (int)(threadIdx.x & 63));
+      });
+      patched = noisy && want;
 #ifdef VQE_STAMPS
       if (threadIdx.x == 0) atomicAdd(A.dbg + 3, (unsigned long long)(clock64() - tt0));
 #endif
