@@ -361,6 +361,11 @@ def main():
             if tr.get("workload") == out["config"]["workload"]:
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = tr["source"]
+        ifile = os.path.join(ROOT, "profiles", "issue_stats.json")
+        if os.path.exists(ifile):      # what actually bounds the LDS-resident kernel (PMC evidence)
+            st = json.load(open(ifile))
+            if st.get("workload") == out["config"]["workload"]:
+                out["roofline"]["issue"] = {k: st[k] for k in st if k not in ("workload", "kernel")}
         if heis is not None:
             out["heis20"] = heis
         if not args.no_cpu_baseline:
