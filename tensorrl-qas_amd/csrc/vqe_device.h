@@ -1146,7 +1146,12 @@ struct StagedCobyla {
   __device__ __forceinline__ void call(Ptr mem, double f, double rhobeg, double rhoend, int maxfun) {
     Cob cob;
     cob.ctx.tid = threadIdx.x & 63;
-    cob.bind(mem, n);
+    // opaque copies: otherwise the array addresses bind() derives are loop invariants of the
+    // evaluation loop, get hoisted out of it, spilled across the energy step (where registers
+    // are scarcest) and reloaded from scratch inside every tell()
+    int nn = n;
+    asm volatile("" : "+v"(mem), "+v"(nn));
+    cob.bind(mem, nn);
     if (FIRST) {
       want = cob.start(rhobeg, rhoend, maxfun);
     } else {
