@@ -947,7 +947,8 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H, Hook
   constexpr int HP = NP / 2;                 // pairs per half group
   constexpr int PD = kEnergyPD;
   static_assert(NP >= 2 && NP <= 8 && PD % 2 == 0, "register energy path: 2..8 pairs per thread");
-  const uint32_t tid = threadIdx.x;
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));   // opaque: address terms derived from it are rebuilt per evaluation, not kept live across the kernel
   const double* __restrict__ tables = H.tables;
   lds_cbyte* psi_l = (lds_cbyte*)L.psi;
   double2 own[NA];

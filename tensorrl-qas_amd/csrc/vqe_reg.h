@@ -232,7 +232,8 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
   constexpr int LT = Geo<N>::LT;
   constexpr int R = N - LT;
   constexpr int NA = 1 << R;
-  const int tid = threadIdx.x;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));   // opaque (see reg_energy)
   for (int j = tid; j < P; j += kThreads) {
     if (j == p_hole) continue;
     double s, c;
