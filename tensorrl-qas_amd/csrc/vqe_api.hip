@@ -136,8 +136,8 @@ std::vector<int> assign_groups(const std::vector<uint32_t>& gx, const std::vecto
 // vectors.  Pauli masks transform as x' = M x, z' = M^-T z.
 struct IndexMap {
   int n = 0;
-  uint32_t row[16] = {0};      // rows of M
-  uint32_t inv_col[16] = {0};  // columns of M^-1 (as bit masks over its rows)
+  uint32_t row[32] = {0};      // rows of M (identity beyond the register path's n <= 13)
+  uint32_t inv_col[32] = {0};  // columns of M^-1 (as bit masks over its rows)
   uint32_t map_x(uint32_t x) const {
     uint32_t r = 0;
     for (int i = 0; i < n; ++i) r |= (uint32_t)(__builtin_popcount(row[i] & x) & 1) << i;
@@ -196,7 +196,7 @@ IndexMap choose_index_map(int n, int lt, const std::vector<uint32_t>& xs) {
   for (int bit = 0; bit < n && filled < lt; ++bit)
     if (independent(1u << bit)) { add_row(1u << bit); m.row[filled++] = 1u << bit; }
   // M^-1 by Gauss-Jordan on [M | I] (rows as bit masks)
-  uint32_t a[16], inv[16];
+  uint32_t a[32], inv[32];
   for (int i = 0; i < n; ++i) { a[i] = m.row[i]; inv[i] = 1u << i; }
   for (int c = 0; c < n; ++c) {
     int piv = c;

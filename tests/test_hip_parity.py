@@ -174,7 +174,7 @@ def test_batch_of_circuits(tq):
             assert nfev[b] == 1
 
 
-@pytest.mark.parametrize("n,G,seed", [(14, 24, 0), (15, 10, 1)])
+@pytest.mark.parametrize("n,G,seed", [(14, 24, 0), (15, 10, 1), (17, 8, 2), (18, 6, 3)])
 def test_streaming_path(tq, n, G, seed):
     rng = np.random.default_rng(300 + seed)
     psi0 = random_state(n, rng)
@@ -514,3 +514,38 @@ def test_bench_workload_parity(tq):
         psi = vo.run_circuit(psi0, kind[i], q0[i], q1[i], pidx[i], xi)
         assert abs(vo.energy_pauli(psi, *ham) - fe[i]) < E_TOL
         assert 1 <= nfev[i] <= 150
+
+
+def test_heisenberg_20q_config(tq):
+    """BASELINE config 4 at full size (20 qubits, 77 terms, 20 X-mask groups): the closed-form
+    energy of |0...0> (19 ZZ bonds + 20 Z = 39), a random-circuit energy against the oracle,
+    and both shardings of the term sum adding up to the unsharded energies of a small batch."""
+    import bench
+    n = 20
+    ham, _ = tq.hamiltonian.heisenberg(n)
+    assert len(ham.coeff) == 77
+    eng = tq.VQEEngine(n)
+    eng.set_hamiltonian(ham.xmask, ham.zmask, ham.coeff)
+    eng.set_circuit(tq.Circuit.empty())
+    assert abs(eng.energy(np.zeros(0)) - 39.0) < E_TOL
+    B, G = 3, 12
+    b = bench.make_batch(tq, n, B, G, 2020)
+    eng.batch_load_flat(b["gate_off"], b["kind"], b["q0"], b["q1"], b["pidx"], b["par_off"], b["theta"])
+    eng.batch_run_energy()
+    full = eng.batch_fetch(want_x=False)[1].copy()
+    psi0 = np.zeros(1 << n, complex)
+    psi0[0] = 1.0
+    kind = b["kind"].reshape(B, G); q0 = b["q0"].reshape(B, G); q1 = b["q1"].reshape(B, G); pidx = b["pidx"].reshape(B, G)
+    th0 = b["theta"][b["par_off"][0]:b["par_off"][1]]
+    ref = vo.energy_pauli(vo.run_circuit(psi0, kind[0], q0[0], q1[0], pidx[0], th0), ham.xmask, ham.zmask, ham.coeff)
+    assert abs(full[0] - ref) < E_TOL
+    for setter in (eng.set_amplitude_shard, eng.set_term_shard):
+        for world in (2, 8):
+            tot = np.zeros(B)
+            for r in range(world):
+                setter(r, world)
+                eng.batch_load_flat(b["gate_off"], b["kind"], b["q0"], b["q1"], b["pidx"], b["par_off"], b["theta"])
+                eng.batch_run_energy()
+                tot += eng.batch_fetch(want_x=False)[1]
+            assert np.abs(tot - full).max() < E_TOL
+        setter(0, 1)
