@@ -8,8 +8,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 t0 = time.time(); cases = 0; worst_e = worst_a = 0.0
 while time.time() - t0 < budget:
-    n = int(rng.choice([1, 2, 3, 5, 6, 8, 9, 10, 11, 12, 13, 14]))
-    G = int(rng.integers(0, 90 if n <= 13 else 24))
+    n = int(rng.choice([1, 2, 3, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18], p=[.07] * 12 + [.04] * 4))
+    G = int(rng.integers(0, 90 if n <= 13 else 16))
     T = int(rng.integers(1, 120))
     psi0 = random_state(n, rng) if rng.random() < 0.8 else None
     ham = random_hamiltonian(n, T, rng, real=bool(rng.random() < 0.5))
@@ -38,6 +38,17 @@ while time.time() - t0 < budget:
         worst_e = max(worst_e, abs(got - ref))
         if abs(got - ref) > 1e-10:
             print("ENERGY MISS", n, G, T, noisy, got, ref); sys.exit(1)
+    if not noisy and rng.random() < 0.3:               # both shardings of the term sum add up
+        full = eng.energy(th)
+        for setter in ((eng.set_term_shard,) if n <= 13 else (eng.set_term_shard, eng.set_amplitude_shard)):
+            world = int(rng.choice([2, 3, 8]))
+            if setter == eng.set_amplitude_shard and world == 3: world = 4
+            tot = 0.0
+            for r in range(world):
+                setter(r, world); tot += eng.energy(th)
+            setter(0, 1)
+            if abs(tot - full) > 1e-10:
+                print("SHARD MISS", n, world, tot, full); sys.exit(1)
     if n <= 13:
         dr = co.noise_draws(seed, 0, 2, kind, p1, p2) if noisy else None
         st = eng.get_state(th)
