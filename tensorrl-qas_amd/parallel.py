@@ -92,8 +92,15 @@ class TermShardedEngine:
         self.engine.batch_copy_energy(self._buf.data_ptr())
         return allreduce_sum(self._buf)
 
+    def partial_energies(self):
+        """This rank's share of the energies of the resident batch (host array, not reduced)."""
+        self.engine.batch_run_energy()
+        return self.engine.batch_fetch(want_x=False)[1]
+
     def minimize(self, circuit, x0, rhobeg=1.0, rhoend=1e-4, maxfun=1000):
+        """Lock-step COBYLA over all ranks on the all-reduced energy (``sharded_minimize`` does
+        the reduction: ``partial`` must return this rank's share only)."""
         def partial(x):
             self.engine.batch_load([circuit], [x])
-            return float(self.energies(1)[0].item())
+            return float(self.partial_energies()[0])
         return sharded_minimize(partial, x0, rhobeg, rhoend, maxfun)
