@@ -32,11 +32,14 @@ class Circuit:
     """Gate list in construct_ansatz order (reference VQE_qulacs_TN_notin_RL.py:13-45):
     parallel int32 arrays ``kind, q0, q1, pidx`` and the number of parameters."""
 
-    __slots__ = ("kind", "q0", "q1", "pidx", "n_params")
+    # ``angles``: optional parameter values carried by the handle (the reference's qulacs
+    # circuit holds its parameters; the VQAs shim uses this)
+    __slots__ = ("kind", "q0", "q1", "pidx", "n_params", "angles")
 
     def __init__(self, kind, q0, q1, pidx, n_params):
         self.kind, self.q0, self.q1, self.pidx = _i32(kind), _i32(q0), _i32(q1), _i32(pidx)
         self.n_params = int(n_params)
+        self.angles = None
 
     def __len__(self):
         return int(self.kind.size)

@@ -289,3 +289,48 @@ def test_term_sharded_engine_two_ranks_on_one_gpu():
         x = np.array(r0[key]["x"])
         assert abs(r0[key]["f"] - vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, x), *ham)) < 1e-10
         assert 1 <= r0[key]["nfev"] <= 40
+
+
+def test_lower_seam_vqa_shim():
+    """The reference's L2 seam names (environments/VQAs/VQE_qulacs_TN_notin_RL.py and the
+    from-|0> twin VQE_qulacs.py): construct_ansatz / get_exp_val / get_energy_qulacs on a state
+    tensor, with a Pauli Hamiltonian and with a dense little-endian operator, against the
+    oracle's ansatz builder + gate sweeps + dense expectation."""
+    import vqe_oracle as vo
+    from helpers import random_hamiltonian, random_state
+    from tensorrl_qas_amd import hamiltonian as hm
+    from tensorrl_qas_amd.environments.VQAs import VQE_qulacs_TN_notin_RL as vc
+    from tensorrl_qas_amd.environments.VQAs import VQE_qulacs as vc0
+    n, L = 5, 7
+    rng = np.random.default_rng(11)
+    state = torch.zeros((L, n + 6, n))
+    for layer in range(L):
+        for _ in range(2):
+            if rng.random() < 0.5:
+                c = int(rng.integers(n)); t = int((c + 1 + rng.integers(n - 1)) % n)
+                state[layer][t][c] = 1
+            else:
+                a, q = int(rng.integers(3)), int(rng.integers(n))
+                state[layer][n + a][q] = 1
+                state[layer][n + 3 + a][q] = float(rng.uniform(-3, 3))
+    psi0 = random_state(n, rng)
+    xs, zs, cs = random_hamiltonian(n, 20, rng)
+    ham = hm.PauliHamiltonian(n, xs, zs, cs)
+    kind, q0, q1, pidx, th = vo.ansatz_from_state(state.numpy(), n)
+    dense = np.zeros((1 << n, 1 << n), complex)
+    idx = np.arange(1 << n)
+    for x, z, w in zip(xs, zs, cs):
+        x, z = int(x), int(z)
+        dense[idx ^ x, idx] += w * (1.0 - 2.0 * vo._parity(idx & z)) * (1j ** bin(x & z).count("1"))
+    ref = vo.energy_dense(vo.run_circuit(psi0, kind, q0, q1, pidx, th), dense)
+    circ = vc.Parametric_Circuit(n).construct_ansatz(state)
+    assert circ.n_params == th.size
+    assert abs(vc.get_exp_val(n, circ, ham, psi0) - ref) < 1e-10
+    assert abs(vc.get_exp_val(n, circ, dense, psi0) - ref) < 1e-10
+    th2 = th + rng.normal(size=th.size)
+    ref2 = vo.energy_dense(vo.run_circuit(psi0, kind, q0, q1, pidx, th2), dense)
+    assert abs(vc.get_energy_qulacs(th2, observable=ham, circuit=circ, n_qubits=n, TN_state=psi0) - ref2) < 1e-10
+    zero = np.zeros(1 << n, complex); zero[0] = 1.0
+    ref0 = vo.energy_dense(vo.run_circuit(zero, kind, q0, q1, pidx, th), dense)
+    circ0 = vc0.Parametric_Circuit(n).construct_ansatz(state)
+    assert abs(vc0.get_exp_val(n, circ0, ham) - ref0) < 1e-10
