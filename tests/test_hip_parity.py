@@ -549,3 +549,45 @@ def test_heisenberg_20q_config(tq):
                 tot += eng.batch_fetch(want_x=False)[1]
             assert np.abs(tot - full).max() < E_TOL
         setter(0, 1)
+
+
+def test_engine_plumbing(tq):
+    """Entry points the benchmark / distributed code rely on: caller-owned stream, device-side
+    energy buffer (pointer + copy), kernel timer, the reduction-only launch of the streaming
+    path, and the raw (pre-float32) optimum of the env-step launch."""
+    import torch
+    rng = np.random.default_rng(5)
+    for n in (12, 14):
+        psi0 = random_state(n, rng)
+        ham = random_hamiltonian(n, 25, rng)
+        eng = _engine(tq, n, psi0, ham)
+        stream = torch.cuda.Stream()
+        eng.set_stream(stream.cuda_stream)
+        raws = [random_gates(n, 12, rng) for _ in range(4)]
+        eng.batch_load([tq.Circuit(*g[:4], g[4].size) for g in raws], [g[4] for g in raws])
+        eng.batch_run_energy()
+        buf = torch.zeros(4, dtype=torch.float64, device="cuda:0")
+        eng.batch_copy_energy(buf.data_ptr())
+        eng.sync()
+        _, f, _ = eng.batch_fetch()
+        assert np.array_equal(buf.cpu().numpy(), f)
+        assert eng.batch_energy_devptr() != 0
+        assert eng.last_kernel_ms() > 0.0
+        for b, g in enumerate(raws):
+            assert abs(f[b] - vo.energy_pauli(vo.run_circuit(psi0, *g), *ham)) < E_TOL
+        if n >= 14:
+            eng.batch_run_reduction()            # states resident: the Pauli reduction alone
+            eng.batch_copy_energy(buf.data_ptr())
+            eng.sync()
+            assert np.array_equal(buf.cpu().numpy(), f)
+        else:
+            with pytest.raises(tq.VQEError):
+                eng.batch_run_reduction()
+            eng.batch_set_new_gate([len(g[0]) - 1 for g in raws])
+            eng.batch_run_env_step(1.0, 1e-4, 30)
+            x, _, _ = eng.batch_fetch()
+            xraw = eng.batch_fetch_xopt()
+            assert np.array_equal(x, xraw.astype(np.float32).astype(np.float64))
+        eng.set_stream(None)
+        eng.batch_run_energy()
+        assert np.array_equal(eng.batch_fetch()[1], f)
