@@ -334,3 +334,36 @@ def test_lower_seam_vqa_shim():
     ref0 = vo.energy_dense(vo.run_circuit(zero, kind, q0, q1, pidx, th), dense)
     circ0 = vc0.Parametric_Circuit(n).construct_ansatz(state)
     assert abs(vc0.get_exp_val(n, circ0, ham) - ref0) < 1e-10
+
+
+def test_trainable_noisy_env_and_structure_rl(data_root):
+    """The two remaining drivers' environments: trainable + noise (environment_qulacs_noise.py,
+    cfg TensorRL_trainable/H2O8q_TNbond2_noise) and StructureRL (zero_param_init: the TN
+    circuit's structure with all angles zeroed, cfg StructureRL/BEH26q_TNbond2)."""
+    from tensorrl_qas_amd.environments.environment_qulacs_noise import CircuitEnv as NoisyEnv
+    from tensorrl_qas_amd.environments.environment_qulacs import CircuitEnv
+    from tensorrl_qas_amd.environments.utils.utils import dictionary_of_actions
+    conf = reference_config("TensorRL_trainable/H2O8q_TNbond2_noise", data_root)
+    conf["non_local_opt"]["global_iters"] = 40
+    env = NoisyEnv(conf, torch.device("cuda:0"), seed=3)
+    obs = env.reset()
+    n = env.num_qubits
+    assert obs.shape[0] == env.num_layers * (n + 3) * n
+    assert int((env.state[:, :n + 3] == 1).sum()) == 150              # the encoded TN circuit
+    table = dictionary_of_actions(n)
+    for ai in (5, 61, 70):
+        obs, rwd, done = env.step(table[ai])
+        assert env.min_eig - 1e-9 <= env.energy <= env.max_eig + 1e-9
+        assert torch.isfinite(rwd) and 1 <= env.nfev <= 40
+    conf = reference_config("StructureRL/BEH26q_TNbond2", data_root)
+    conf["non_local_opt"]["global_iters"] = 60
+    env = CircuitEnv(conf, torch.device("cuda:0"))
+    env.reset()
+    n = env.num_qubits
+    assert float(env.state[:, n + 3:].abs().sum()) == 0.0               # zero_param_init
+    # all angles zero: rotations are identities, CNOTs permute |0..0> onto itself
+    case = load_case("BEH2_6q")
+    zero = np.eye(1, 2 ** n)[0].astype(complex)
+    assert abs(env.prev_energy - _oracle_energy(env, env.state, zero, case, reverse=True)) < E_TOL
+    obs, rwd, done = env.step(dictionary_of_actions(n)[n * (n - 1) + 4])
+    assert abs(env.energy - _oracle_energy(env, env.state, zero, case, reverse=True)) < E_TOL
