@@ -591,3 +591,46 @@ def test_engine_plumbing(tq):
         eng.set_stream(None)
         eng.batch_run_energy()
         assert np.array_equal(eng.batch_fetch()[1], f)
+
+
+def test_raw_ctypes_binding_as_documented():
+    """the C ABI bound with plain ctypes (no helper module), in the order a
+    maintainer would call it: create, init state, Hamiltonian, circuit, energy, COBYLA."""
+    import ctypes as C
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = C.CDLL(os.path.join(root, "tensorrl-qas_amd", "libvqe_hip.so"))
+    lib.vqe_last_error.restype = C.c_char_p
+    lib.vqe_minimize_cobyla.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int,
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    n = 6
+    rng = np.random.default_rng(9)
+    psi0 = random_state(n, rng)
+    xm, zm, w = random_hamiltonian(n, 15, rng)
+    kind, q0, q1, pidx, th = random_gates(n, 12, rng)
+    dp, u64p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+    h = C.c_void_p()
+    assert lib.vqe_create(n, 0, C.byref(h)) == 0
+    tn = np.ascontiguousarray(psi0)
+    assert lib.vqe_set_init_state(h, tn.view(np.float64).ctypes.data_as(dp)) == 0
+    xm, zm, w = (np.ascontiguousarray(a) for a in (xm.astype(np.uint64), zm.astype(np.uint64), np.asarray(w, np.float64)))
+    assert lib.vqe_set_hamiltonian_pauli(h, len(w), xm.ctypes.data_as(u64p), zm.ctypes.data_as(u64p), w.ctypes.data_as(dp)) == 0
+    k, a, b, p = (np.ascontiguousarray(v, np.int32) for v in (kind, q0, q1, pidx))
+    assert lib.vqe_set_circuit(h, len(k), k.ctypes.data_as(i32p), a.ctypes.data_as(i32p), b.ctypes.data_as(i32p),
+                               p.ctypes.data_as(i32p), int(th.size)) == 0
+    e = C.c_double()
+    theta = np.ascontiguousarray(th, np.float64)
+    assert lib.vqe_energy(h, theta.ctypes.data_as(dp), C.byref(e)) == 0
+    assert abs(e.value - vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th), xm, zm, w)) < E_TOL
+    x = np.zeros_like(theta)
+    f = C.c_double()
+    nfev = C.c_int32()
+    assert lib.vqe_minimize_cobyla(h, theta.ctypes.data_as(dp), 1.0, 1e-4, 50, x.ctypes.data_as(dp), C.byref(f), C.byref(nfev)) == 0
+    assert abs(f.value - vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, x), xm, zm, w)) < E_TOL
+    assert f.value <= e.value + 1e-12 and 1 <= nfev.value <= 50
+    # error behaviour: negative code + message, nothing thrown across the ABI
+    assert (p >= 0).any()
+    rc = lib.vqe_set_circuit(h, len(k), k.ctypes.data_as(i32p), a.ctypes.data_as(i32p), b.ctypes.data_as(i32p),
+                             p.ctypes.data_as(i32p), 0)          # parameter indices out of range
+    assert rc < 0 and len(lib.vqe_last_error(h)) > 0
+    lib.vqe_destroy(h)
