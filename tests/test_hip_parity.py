@@ -634,3 +634,32 @@ def test_raw_ctypes_binding_as_documented():
                              p.ctypes.data_as(i32p), 0)          # parameter indices out of range
     assert rc < 0 and len(lib.vqe_last_error(h)) > 0
     lib.vqe_destroy(h)
+
+
+def test_noisy_minimize_is_a_pure_function_of_the_seed(tq):
+    """Stochastic env-step launches: same seed -> bit-identical (x, f, nfev); another seed or
+    another stream of the batch -> another trajectory.  (Every f belongs to the noise
+    realisation of its own evaluation; the per-evaluation energies themselves are pinned by
+    test_noise_trajectories_match_oracle.)"""
+    n = 10
+    rng = np.random.default_rng(31)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 30, rng)
+    base = random_gates(n, 20, rng)
+    kind, q0, q1, pidx = [], [], [], []
+    for k, a, b, p in zip(*base[:4]):
+        kind.append(k), q0.append(a), q1.append(b), pidx.append(p)
+        kind.append(5 if k == 0 else 4), q0.append(a), q1.append(b if k == 0 else -1), pidx.append(-1)
+    circ = tq.Circuit(kind, q0, q1, pidx, base[4].size)
+    outs = []
+    for seed in (77, 77, 78):
+        eng = _engine(tq, n, psi0, ham)
+        eng.set_noise(0.05, 0.1, seed)
+        eng.batch_load([circ] * 3, [base[4]] * 3)
+        eng.batch_set_new_gate([len(kind) - 2] * 3)
+        eng.batch_run_env_step(1.0, 1e-4, 60)
+        outs.append(tuple(np.copy(v) for v in eng.batch_fetch()))
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
+    assert not np.array_equal(outs[0][1], outs[2][1])
+    # streams of one batch see different noise realisations
+    assert len(set(outs[0][1].tolist())) == 3
