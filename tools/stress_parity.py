@@ -6,7 +6,7 @@ import tensorrl_qas_amd as tq, vqe_oracle as vo, c_oracle as co
 from helpers import random_gates, random_hamiltonian, random_state
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
-t0 = time.time(); cases = 0; worst_e = worst_a = 0.0
+t0 = time.time(); cases = 0; worst_e = worst_a = 0.0; t_rep = t0
 while time.time() - t0 < budget:
     n = int(rng.choice([1, 2, 3, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18], p=[.07] * 12 + [.04] * 4))
     G = int(rng.integers(0, 90 if n <= 13 else 16))
@@ -79,4 +79,6 @@ while time.time() - t0 < budget:
                 if abs(ref - f[bb]) > 1e-10:
                     print("ENV-STEP MISS", n, bb, f[bb], ref); sys.exit(1)
     cases += 1
+    if time.time() - t_rep > 30:
+        t_rep = time.time(); print(f"  ... {cases} cases, worst |dE| {worst_e:.2e}", flush=True)
 print(f"stress: {cases} random cases in {time.time()-t0:.0f} s, worst |dE| {worst_e:.2e}, worst |d amp| {worst_a:.2e}")
