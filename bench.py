@@ -368,7 +368,7 @@ def main():
                 out["roofline"]["issue"] = {k: st[k] for k in st if k not in ("workload", "kernel")}
         if heis is not None:
             out["heis20"] = heis
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(tq, ham, psi0, batch, G, args.cpu_steps, args.maxfun)
         print(json.dumps(out), flush=True)
     if world > 1:
