@@ -446,7 +446,7 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   int max_ops = 1, max_par = 1;
   for (int b = 0; b < batch; ++b) {
     sbeg[b] = stot;
-    stot += (int64_t)cby::scratch_doubles(pcnt[b], 8);
+    stot += (int64_t)cby::scratch_doubles(pcnt[b], 16);   // the larger of the device contexts' paddings
     stot = (stot + 1) & ~(int64_t)1;  // keep 16-byte alignment
     max_par = std::max(max_par, (int)pcnt[b]);
     int ops = 0;

@@ -259,6 +259,72 @@ struct WaveCtx {
   }
 };
 
+// Workgroup-wide context of cobyla_m0.h for LARGE problems (more rows than a wave has lanes,
+// matrices in the global scratch - the trainable-path regime, ~129 parameters): every thread
+// takes a row, reductions go through LDS and s_barrier.  With one wave the row loops would run
+// several passes of a latency-bound inner loop over L2/HBM-resident matrices.
+template <int NT>
+struct BlockCtx {
+  int tid;
+  double* red;   // >= 12 doubles of LDS (NW sums + NW indices)
+  static constexpr int nth = NT;
+  static constexpr int NW = NT / 64;
+  static constexpr int kPad = 8;
+  static constexpr bool kSplit = false;
+  __device__ __forceinline__ double pair_sum(double v) const { return v; }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ int all_or(int v) const {   // (HIP's __syncthreads_or allocates static LDS)
+    const int any = __ballot(v != 0) != 0ull;
+    int* ired = (int*)(red + NW);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) ired[threadIdx.x >> 6] = any;
+    __syncthreads();
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) r |= ired[w];
+    return r != 0;
+  }
+  template <class F>
+  __device__ __forceinline__ double sum(int n, F f) const {
+    double a = 0.0;
+    for (int i = tid; i < n; i += NT) a += f(i);
+    return block_sum<NW>(a, red);
+  }
+  template <class F>
+  __device__ __forceinline__ int arg_first(int n, F f, double thresh, bool want_max, double* val) const {
+    double best = thresh;
+    int idx = 0x7fffffff;
+    for (int i = tid; i < n; i += NT) {
+      const double v = f(i);
+      if (want_max ? (v > best) : (v < best)) { best = v; idx = i; }
+    }
+    auto merge = [&](double ob, int oi) {
+      const bool better = want_max ? (ob > best) : (ob < best);
+      if (better || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    };
+    merge(dpp_f64<0xB1>(best), dpp_i32<0xB1>(idx));
+    merge(dpp_f64<0x4E>(best), dpp_i32<0x4E>(idx));
+    merge(dpp_f64<0x141>(best), dpp_i32<0x141>(idx));
+    merge(dpp_f64<0x140>(best), dpp_i32<0x140>(idx));
+    const double b0 = best;
+    const int i0 = idx;
+    best = readlane_f64(b0, 0); idx = __builtin_amdgcn_readlane(i0, 0);
+    merge(readlane_f64(b0, 16), __builtin_amdgcn_readlane(i0, 16));
+    merge(readlane_f64(b0, 32), __builtin_amdgcn_readlane(i0, 32));
+    merge(readlane_f64(b0, 48), __builtin_amdgcn_readlane(i0, 48));
+    int* ired = (int*)(red + NW);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = best; ired[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    best = red[0]; idx = ired[0];
+#pragma unroll
+    for (int wv = 1; wv < NW; ++wv) merge(red[wv], ired[wv]);
+    __syncthreads();   // red is reused by the next reduction
+    *val = best;
+    return idx == 0x7fffffff ? -1 : idx;
+  }
+};
+
 // LDS carve-up of one workgroup.
 
 struct GroupMeta { uint32_t x; int32_t hb; int32_t off_r; int32_t off_i; };
@@ -1107,7 +1173,10 @@ template <int N>
 struct StagedCobyla {
   static constexpr int kThreads = Geo<N>::NT;
   typedef cby::CobylaM0<WaveCtx, false, lds_double> CobL;   // arrays in LDS (ds_ instructions)
-  typedef cby::CobylaM0<WaveCtx, false, double> CobG;       // arrays in the global scratch
+  typedef cby::CobylaM0<WaveCtx, false, double> CobG;       // arrays in the global scratch, one wave
+  typedef cby::CobylaM0<BlockCtx<Geo<N>::NT>, false, double> CobB;   // the same, whole workgroup (more rows than a wave has lanes)
+  double* red;     // LDS words of the block reductions
+  bool block;      // more rows than a wave has lanes: workgroup-wide context on the global scratch
   double* gmem;    // per-problem scratch; x[] is its first array
   double* lmem;    // the (dead) state region of LDS
   int* pub;        // LDS: what wave 0 publishes to the workgroup after a call
@@ -1120,7 +1189,12 @@ struct StagedCobyla {
     pub = (int*)(L.red + 8);
     n = n_;
     words = (int)cby::scratch_doubles(n, WaveCtx::kPad);
-    staged = (size_t)words * 8 <= ((size_t)16 << N);
+    red = L.red;
+    // (n <= 9: the 128-VGPR kernels lose 10-20 % to spills when a third variant is compiled in,
+    // and gain only 13 % at ~129 parameters: they keep the single-wave variants)
+    block = N >= 10 && n > 64;
+    staged = !block && (size_t)words * 8 <= ((size_t)16 << N);
+    if (block) words = (int)cby::scratch_doubles(n, BlockCtx<Geo<N>::NT>::kPad);
   }
   __device__ __forceinline__ double* x() const { return gmem; }
   // the optimiser's scalars as parked in the scratch (valid after start()/tell())
@@ -1146,12 +1220,13 @@ struct StagedCobyla {
   template <bool FIRST, class Cob, class Ptr>
   __device__ __forceinline__ void call(Ptr mem, double f, double rhobeg, double rhoend, int maxfun) {
     Cob cob;
-    cob.ctx.tid = threadIdx.x & 63;
+    cob.ctx.tid = Cob::P == 0 ? 0 : (int)(threadIdx.x % (unsigned)decltype(cob.ctx)::nth);
+    if constexpr (decltype(cob.ctx)::nth != 64) cob.ctx.red = red;
     // opaque copies: otherwise the array addresses bind() derives are loop invariants of the
     // evaluation loop, get hoisted out of it, spilled across the energy step (where registers
     // are scarcest) and reloaded from scratch inside every tell()
     int nn = n;
-    asm volatile("" : "+v"(mem), "+v"(nn));
+    if constexpr (N >= 10) asm volatile("" : "+s"(mem), "+s"(nn));   // (uniform: scalar registers; n <= 9: measured -15 %)
     cob.bind(mem, nn);
     if (FIRST) {
       want = cob.start(rhobeg, rhoend, maxfun);
@@ -1173,7 +1248,12 @@ struct StagedCobyla {
 #ifdef VQE_STAMPS
     const long long t1 = clock64();
 #endif
-    if (threadIdx.x < 64) {
+    if (N >= 10 && block) {
+      if constexpr (N >= 10) {
+        if (threadIdx.x >= 64 && threadIdx.x < 128) side();
+        call<FIRST, CobB>(gmem, f, rhobeg, rhoend, maxfun);     // all threads: contains barriers
+      }
+    } else if (threadIdx.x < 64) {
       if (staged) call<FIRST, CobL>((lds_double*)lmem, f, rhobeg, rhoend, maxfun);
       else call<FIRST, CobG>(gmem, f, rhobeg, rhoend, maxfun);
     } else if (threadIdx.x < 128) {

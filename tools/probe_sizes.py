@@ -3,8 +3,12 @@ import sys, numpy as np
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/oracle')
 import tensorrl_qas_amd as tq, bench
 from test_hip_parity import random_state, random_hamiltonian
-for n, T, G, B, mf in ((6, 34, 40, 4096, 300), (8, 193, 40, 4096, 300), (10, 300, 48, 4096, 300), (11, 400, 56, 2048, 300),
-                       (12, 631, 64, 2048, 300), (13, 300, 64, 1024, 300)):
+SIZES = ((6, 34, 40, 4096, 300), (8, 193, 40, 4096, 300), (10, 300, 48, 4096, 300), (11, 400, 56, 2048, 300),
+         (12, 631, 64, 2048, 300), (13, 300, 64, 1024, 300))
+only = [int(a) for a in sys.argv[1:]]
+for n, T, G, B, mf in SIZES:
+    if only and n not in only:
+        continue
     rng = np.random.default_rng(n)
     psi0 = random_state(n, rng)
     if n == 12:
