@@ -102,9 +102,9 @@ CBY_HD int lead_dim(int nv) { return nv | 1; }
 CBY_HD int padded(int n, int pad) { return (n + pad - 1) / pad * pad; }
 
 CBY_HD size_t scratch_doubles(int n, int pad = 8) {
-  // x, sim, simi, datmat, a, vsig, veta, sigbar, dx, w, state
+  // x, sim, simi, datmat, a, vsig, veta, sigbar, dx, w, tdot, state
   const size_t nv = (size_t)padded(n, pad), ld = (size_t)lead_dim((int)nv);
-  return nv + (nv + 1) * ld + nv * ld + (nv + 1) + 6 * nv + 2 + kStateDoubles;
+  return nv + (nv + 1) * ld + nv * ld + (nv + 1) + 7 * nv + 2 + kStateDoubles;
 }
 
 // Real is `double`, or an address-space qualified double (LDS) on the device so that the
@@ -121,7 +121,7 @@ struct CobylaM0 {
   bool split;
   double rhoend;
   // shared (per problem) arrays
-  Real *x, *sim, *simi, *datmat, *a, *vsig, *veta, *sigbar, *dx, *w, *st;
+  Real *x, *sim, *simi, *datmat, *a, *vsig, *veta, *sigbar, *dx, *w, *tdot, *st;
   // scalars, identical in every thread
   double rho, prerem, parsig, pareta, fbest_ret;
   int nfvals, jdrop, ibrnch, iflag, ifull, status;
@@ -143,6 +143,7 @@ struct CobylaM0 {
     sigbar = mem; mem += nv;
     dx = mem; mem += nv;
     w = mem; mem += nv + 2;
+    tdot = mem; mem += nv;     // signed simi_j . dx of the trust-region branch, reused by update_simi
     st = mem;
     split = Ctx::kSplit && 2 * nv <= ctx.nth;
     if (split) {
@@ -412,7 +413,7 @@ struct CobylaM0 {
           SIM(i, jdrop) = d;
         }
         ctx.sync();
-        update_simi();
+        update_simi(false);
         for (int j = ctx.tid; j < n; j += ctx.nth) x[j] = SIM(j, nv) + dx[j];
         ctx.sync();
         return request_eval();  // ibrnch == 0: the value lands in datmat[jdrop]
@@ -448,6 +449,7 @@ struct CobylaM0 {
             for (int q = 0; q < P; ++q) t += v[q] * u[q];
           }
           if (split) t = ctx.pair_sum(t);
+          tdot[j] = t;
           t = fabs(t);
           w[j] = t;
           sigbar[j] = t * vsig[j];
@@ -486,7 +488,7 @@ struct CobylaM0 {
         if (ctx.tid == 0) datmat[jdrop] = f;
         ctx.sync();
         CBY_STAMP(1);
-        update_simi();
+        update_simi(true);     // tdot[] still holds simi_j . dx for this dx
         CBY_STAMP(2);
         if (trured > 0.0 && trured >= 0.1 * prerem) { lbl = 140; continue; }
         lbl = 550;
@@ -506,22 +508,28 @@ struct CobylaM0 {
   }
 
   // Rank-one update of SIMI after vertex jdrop was replaced by pole + dx.
-  CBY_HD void update_simi() {
-    const double temp = ctx.sum(n, [&](int i) { return SIMI(jdrop, i) * dx[i]; });
+  // have_tdot: tdot[j] = sum_i SIMI(j, i) * dx[i] was left by the caller (same accumulation
+  // order as the loops below would use: identical bits, one pass over simi saved).
+  CBY_HD void update_simi(bool have_tdot) {
+    const double temp = have_tdot ? (double)tdot[jdrop] : ctx.sum(n, [&](int i) { return SIMI(jdrop, i) * dx[i]; });
     ctx.sync();
     for (int i = ctx.tid; i < n; i += ctx.nth) SIMI(jdrop, i) /= temp;
     ctx.sync();
     for (int j = rlane; j < n; j += rstep) {
       if (j == jdrop) continue;
       double t = 0.0;
-      for (int i0 = ilo; i0 < ihi; i0 += P) {
-        double v[P], u[P];
-        CBY_FULL_UNROLL
-        for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = dx[i0 + q]; }
-        CBY_FULL_UNROLL
-        for (int q = 0; q < P; ++q) t += v[q] * u[q];
+      if (have_tdot) {
+        t = tdot[j];
+      } else {
+        for (int i0 = ilo; i0 < ihi; i0 += P) {
+          double v[P], u[P];
+          CBY_FULL_UNROLL
+          for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = dx[i0 + q]; }
+          CBY_FULL_UNROLL
+          for (int q = 0; q < P; ++q) t += v[q] * u[q];
+        }
+        if (split) t = ctx.pair_sum(t);
       }
-      if (split) t = ctx.pair_sum(t);
       for (int i0 = ilo; i0 < ihi; i0 += P) {
         double v[P], u[P];
         CBY_FULL_UNROLL
