@@ -53,7 +53,20 @@ SIGNATURES = {
     "vqe_cobyla_destroy": (None, [vp]),
 }
 
+# include/mps2qc_hip.h (libmps2qc_hip.so: the offline MPS -> PQC fit)
+MPS2QC_LIB_PATH = os.environ.get("MPS2QC_HIP_LIB") or os.path.join(_HERE, "libmps2qc_hip.so")
+MPS2QC_SIGNATURES = {
+    "mps2qc_brickwork_sites": (C.c_int, [C.c_int, C.c_int, c_i32p, C.c_int]),
+    "mps2qc_fit_brickwork": (C.c_int, [C.c_int, C.c_int, C.c_int, c_i32p, C.c_int, c_f64p, C.c_int, c_f64p,
+                                       C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                       C.c_int, C.c_double, C.c_double, C.c_int,
+                                       c_f64p, c_f64p, c_f64p, c_f64p, c_i32p, c_f64p, c_f64p,
+                                       C.POINTER(C.c_float)]),
+    "mps2qc_last_error": (C.c_char_p, []),
+}
+
 _lib = None
+_lib_mps2qc = None
 
 
 class VQEError(RuntimeError):
@@ -75,3 +88,18 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def load_mps2qc():
+    """Load libmps2qc_hip.so once; raises VQEError when it has not been built."""
+    global _lib_mps2qc
+    if _lib_mps2qc is None:
+        if not os.path.exists(MPS2QC_LIB_PATH):
+            raise VQEError(f"{MPS2QC_LIB_PATH} not found: build it with __graft_entry__.build(); no CPU fallback.")
+        lib = C.CDLL(MPS2QC_LIB_PATH)
+        for name, (res, args) in MPS2QC_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib_mps2qc = lib
+    return _lib_mps2qc

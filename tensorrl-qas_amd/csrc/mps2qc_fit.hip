@@ -1,0 +1,599 @@
+// mps2qc_fit.hip - MPS -> brickwork-PQC fit on MI355X (gfx950): C ABI of include/mps2qc_hip.h.
+//
+// One workgroup = one fit (one target state, one random start) for the WHOLE optimisation loop
+// of the reference (dmrg-to-qc/stiefel_opt.py:91-152): per step
+//   forward   psi = U_G ... U_1 |0>                      (state resident in LDS)
+//   loss      o = <t|psi>, L = 1 - |o|                   (dmrg-to-qc/mps2qc.py:283-293)
+//   backward  for k = G..1: psi <- U_k^H psi (the gates are unitary: nothing is stored),
+//             E_k[a,b] = sum_r conj(phi[a,r]) psi[b,r]   (a 4 x 2^(n-2) x 4 complex GEMM, on the
+//             matrix cores: v_mfma_f64_16x16x4_f64), phi <- U_k^H phi
+//   update    StiefelAdam.update (stiefel_opt.py:297-347) for all gates, 16 lanes per 4x4 matrix
+// The reference obtains E_k by jax autodiff through a quimb contraction; o is linear in every
+// gate, so dL/dU_k follows from E_k in closed form (see euclid_grads in the oracle).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/mps2qc_hip.h"
+
+namespace {
+
+enum { E_OK = 0, E_INVAL = -22, E_NOMEM = -12, E_NODEV = -19, E_HIP = -5 };
+thread_local char g_err[256] = "";
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMat = 16;          // complex entries of a gate
+constexpr int kSlotMats = 10;     // LDS matrices per 16-lane update group
+constexpr int kLdsLimit = 160 * 1024;
+
+struct FitArgs {
+  int G, max_iter, frozen, use_mfma, target_shared;
+  double beta1, beta2, eps, tol, param_tol;
+  const int* lo;          // [G] low bit of each gate's qubit pair
+  const double* lr_t;     // [max_iter] bias-corrected learning rate of step it+1
+  const double2* target;  // [B or 1][2^n]
+  const double2* init;    // [B][G][16]
+  double2* final_g;       // [B][G][16]
+  double2* best_g;        // [B][G][16]
+  double2* mom;           // [B][G][16]
+  double2* vel;           // [B][G][16]
+  double* hist;           // [B][max_iter]
+  double* best_val;       // [B]
+  int* n_iter;            // [B]
+  double2* envs;          // [B][G][16]
+  double2* overlap;       // [B]
+  // LDS layout (bytes from the start of dynamic LDS), decided by the host
+  int off_u, off_e, off_red, off_sc, off_dn, off_lo, off_scratch;
+};
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cmulc(double2 a, double2 b) {  // a * conj(b)
+  return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cscale(double s, double2 a) { return make_double2(s * a.x, s * a.y); }
+__device__ __forceinline__ double2 cinv(double2 a) {
+  double d = 1.0 / (a.x * a.x + a.y * a.y);
+  return make_double2(a.x * d, -a.y * d);
+}
+__device__ __forceinline__ double2 csqrt_principal(double2 z) {
+  double ax = fabs(z.x), ay = fabs(z.y);
+  if (ax == 0.0 && ay == 0.0) return make_double2(0.0, z.y);
+  double h = hypot(z.x, z.y);
+  double t = sqrt(0.5 * (h + ax));
+  if (z.x >= 0.0) return make_double2(t, z.y / (2.0 * t));
+  return make_double2(ay / (2.0 * t), copysign(t, z.y));
+}
+__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// 4x4 gate (or its adjoint) from LDS into registers: wave-uniform broadcast reads.
+__device__ __forceinline__ void load_gate(double2 (&m)[16], const double2* M, bool dagger) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      double2 v = dagger ? M[b * 4 + a] : M[a * 4 + b];
+      if (dagger) v.y = -v.y;
+      m[a * 4 + b] = v;
+    }
+}
+
+// st <- m on the qubit pair whose low bit is `lo`; every thread owns whole 4-vectors.
+template <int N, int NT>
+__device__ __forceinline__ void apply_gate(double2* st, const double2 (&m)[16], int lo, int tid) {
+  constexpr int R = 1 << (N - 2);
+  const int lmask = (1 << lo) - 1;
+  for (int r = tid; r < R; r += NT) {
+    const int base = ((r >> lo) << (lo + 2)) | (r & lmask);
+    double2 v[4], w[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) v[b] = st[base | (b << lo)];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double2 s = cmul(m[a * 4], v[0]);
+#pragma unroll
+      for (int b = 1; b < 4; ++b) s = cadd(s, cmul(m[a * 4 + b], v[b]));
+      w[a] = s;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) st[base | (a << lo)] = w[a];
+  }
+}
+
+// Environment partials on the matrix cores.  One v_mfma_f64_16x16x4_f64 consumes 8 values of
+// r: rows (s, c, a) = (r-slice, re/im, row of the gate) of A = phi, columns (s', c', b) of
+// B = psi, k = 4 values of r per slice; only the s == s' blocks are meaningful and kept.
+// A[i][k]: lane = i + 16 k; C[row][col]: col = lane & 15, row = (lane >> 4) + 4 reg.
+template <int N, int NT>
+__device__ __forceinline__ void env_mfma(const double2* phi, const double2* psi, int lo, double* red,
+                                         int tid) {
+  constexpr int R = 1 << (N - 2);
+  constexpr int NW = NT / 64;
+  constexpr int CH = (R + 7) / 8;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, k = lane >> 4;
+  const int s = i >> 3, c = (i >> 2) & 1, a = i & 3;
+  const int lmask = (1 << lo) - 1;
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int ch = wave; ch < CH; ch += NW) {
+    const int r = ch * 8 + s * 4 + k;
+    double av = 0.0, bv = 0.0;
+    if (R >= 8 || r < R) {
+      const int idx = ((r >> lo) << (lo + 2)) | (a << lo) | (r & lmask);
+      av = reinterpret_cast<const double*>(phi)[2 * idx + c];
+      bv = reinterpret_cast<const double*>(psi)[2 * idx + c];
+    }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) red[(wave * 4 + reg) * 64 + lane] = acc[reg];
+}
+
+// E[a][b] from the MFMA partials: M_cc'[a][b] sits at reg = 2 s + c, lane = 16 a + 8 s + 4 c' + b.
+template <int NT>
+__device__ __forceinline__ double2 env_mfma_combine(const double* red, int t) {
+  constexpr int NW = NT / 64;
+  const int a = t >> 2, b = t & 3;
+  double m00 = 0, m01 = 0, m10 = 0, m11 = 0;
+  for (int w = 0; w < NW; ++w)
+    for (int s = 0; s < 2; ++s) {
+      const double* p = red + w * 256;
+      const int ln = a * 16 + s * 8 + b;
+      m00 += p[(2 * s) * 64 + ln];
+      m01 += p[(2 * s) * 64 + ln + 4];
+      m10 += p[(2 * s + 1) * 64 + ln];
+      m11 += p[(2 * s + 1) * 64 + ln + 4];
+    }
+  return make_double2(m00 + m11, m01 - m10);
+}
+
+// The same partials with vector FMAs and a cross-lane reduction (A/B variant).
+template <int N, int NT>
+__device__ __forceinline__ void env_valu(const double2* phi, const double2* psi, int lo, double* red,
+                                         int tid) {
+  constexpr int R = 1 << (N - 2);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lmask = (1 << lo) - 1;
+  double2 acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = make_double2(0.0, 0.0);
+  for (int r = tid; r < R; r += NT) {
+    const int base = ((r >> lo) << (lo + 2)) | (r & lmask);
+    double2 f[4], p[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      f[b] = phi[base | (b << lo)];
+      p[b] = psi[base | (b << lo)];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a * 4 + b] = cadd(acc[a * 4 + b], cmulc(p[b], f[a]));
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    double x = acc[e].x, y = acc[e].y;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      x += shfl_xor_d(x, m);
+      y += shfl_xor_d(y, m);
+    }
+    if (lane == 0) {
+      red[wave * 32 + 2 * e] = x;
+      red[wave * 32 + 2 * e + 1] = y;
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ double2 env_valu_combine(const double* red, int t) {
+  constexpr int NW = NT / 64;
+  double x = 0, y = 0;
+  for (int w = 0; w < NW; ++w) {
+    x += red[w * 32 + 2 * t];
+    y += red[w * 32 + 2 * t + 1];
+  }
+  return make_double2(x, y);
+}
+
+template <int N, int NT>
+__global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int DIM = 1 << N;
+  constexpr int NW = NT / 64;
+  constexpr int SLOTS = NT / 16;
+  double2* psi = reinterpret_cast<double2*>(smem);
+  double2* phi = psi + DIM;
+  double2* U = reinterpret_cast<double2*>(smem + A.off_u);
+  double2* E = reinterpret_cast<double2*>(smem + A.off_e);
+  double* red = reinterpret_cast<double*>(smem + A.off_red);
+  double* sc = reinterpret_cast<double*>(smem + A.off_sc);
+  double* dnorm = reinterpret_cast<double*>(smem + A.off_dn);
+  int* lo_s = reinterpret_cast<int*>(smem + A.off_lo);
+  double2* scratch = reinterpret_cast<double2*>(smem + A.off_scratch);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = A.G;
+  const long inst = blockIdx.x;
+  const double2* tgt = A.target + (A.target_shared ? 0 : inst * (long)DIM);
+  const long gbase = inst * (long)G * kMat;
+
+  for (int e = tid; e < G * kMat; e += NT) {
+    U[e] = A.init[gbase + e];
+    if (!A.frozen) {
+      A.mom[gbase + e] = make_double2(0.0, 0.0);
+      A.vel[gbase + e] = make_double2(0.0, 0.0);
+    }
+  }
+  for (int k = tid; k < G; k += NT) lo_s[k] = A.lo[k];
+  __syncthreads();
+
+  double best_val = 10000.0;  // stiefel_opt.py:122
+  int it = 0;
+  for (; it < A.max_iter;) {
+    // ---- forward
+    for (int i = tid; i < DIM; i += NT) psi[i] = make_double2(i == 0 ? 1.0 : 0.0, 0.0);
+    __syncthreads();
+    for (int k = 0; k < G; ++k) {
+      double2 m[16];
+      load_gate(m, U + k * kMat, false);
+      apply_gate<N, NT>(psi, m, lo_s[k], tid);
+      __syncthreads();
+    }
+    // ---- overlap o = <t|psi>, phi <- t
+    {
+      double2 part = make_double2(0.0, 0.0);
+      for (int i = tid; i < DIM; i += NT) {
+        const double2 t = tgt[i];
+        phi[i] = t;
+        part = cadd(part, cmulc(psi[i], t));
+      }
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) {
+        part.x += shfl_xor_d(part.x, m);
+        part.y += shfl_xor_d(part.y, m);
+      }
+      if (lane == 0) {
+        sc[2 * wave] = part.x;
+        sc[2 * wave + 1] = part.y;
+      }
+    }
+    __syncthreads();
+    {
+      double2 m[16];
+      load_gate(m, U + (G - 1) * kMat, true);
+      apply_gate<N, NT>(psi, m, lo_s[G - 1], tid);
+    }
+    __syncthreads();
+    double2 o = make_double2(0.0, 0.0);
+    for (int w = 0; w < NW; ++w) o = cadd(o, make_double2(sc[2 * w], sc[2 * w + 1]));
+    const double abso = hypot(o.x, o.y);
+    const double val = 1.0 - abso;
+    const double2 ph = make_double2(o.x / abso, o.y / abso);
+
+    // ---- backward: environments
+    for (int k = G - 1; k >= 0; --k) {
+      if (A.use_mfma) env_mfma<N, NT>(phi, psi, lo_s[k], red, tid);
+      else env_valu<N, NT>(phi, psi, lo_s[k], red, tid);
+      __syncthreads();
+      if (tid < 16)
+        E[k * kMat + tid] = A.use_mfma ? env_mfma_combine<NT>(red, tid) : env_valu_combine<NT>(red, tid);
+      if (k > 0) {  // nothing reads phi_0 / psi_{-1}
+        double2 m[16];
+        load_gate(m, U + k * kMat, true);
+        apply_gate<N, NT>(phi, m, lo_s[k], tid);
+        load_gate(m, U + (k - 1) * kMat, true);
+        apply_gate<N, NT>(psi, m, lo_s[k - 1], tid);
+      }
+      __syncthreads();
+    }
+    if (A.envs)
+      for (int e = tid; e < G * kMat; e += NT) A.envs[gbase + e] = E[e];
+    if (A.overlap && tid == 0) A.overlap[inst] = o;
+
+    // ---- StiefelAdam.update, 16 lanes per gate; scratch overlays the idle state vectors
+    const double lr = A.lr_t[it];
+    const int sub = tid & 15, slot = tid >> 4;
+    const int i = sub >> 2, j = sub & 3;
+    double2* S = scratch + slot * (kSlotMats * kMat);
+    __syncthreads();
+    for (int chunk = 0; chunk * SLOTS < G; ++chunk) {
+      const int k = chunk * SLOTS + slot;
+      const bool act = k < G;
+      const int kk = act ? k : 0;
+      const double2* Uk = U + kk * kMat;
+      const double2 u = Uk[sub];
+      const double2 Ee = E[kk * kMat + sub];
+      // Euclidean gradient handed to update(): -(o/|o|) conj(E)
+      const double2 g = cmul(make_double2(-ph.x, -ph.y), make_double2(Ee.x, -Ee.y));
+      S[0 * kMat + sub] = g;
+      __syncthreads();
+      double2 t1 = make_double2(0.0, 0.0);  // U G^H
+#pragma unroll
+      for (int l = 0; l < 4; ++l) t1 = cadd(t1, cmulc(Uk[i * 4 + l], S[0 * kMat + j * 4 + l]));
+      S[1 * kMat + sub] = t1;
+      __syncthreads();
+      double2 rg = g;  // riemannian gradient G - U G^H U (:36-42)
+#pragma unroll
+      for (int l = 0; l < 4; ++l) rg = csub(rg, cmul(S[1 * kMat + i * 4 + l], Uk[l * 4 + j]));
+      double met = rg.x * rg.x + rg.y * rg.y;  // Re tr(rg^H rg) (:84-90)
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) met += shfl_xor_d(met, m);
+      double2 m0 = make_double2(0.0, 0.0), v0 = make_double2(0.0, 0.0);
+      if (!A.frozen) {
+        m0 = A.mom[gbase + kk * kMat + sub];
+        v0 = A.vel[gbase + kk * kMat + sub];
+      }
+      const double2 mom = cadd(cscale(A.beta1, m0), cscale(1.0 - A.beta1, rg));
+      double2 vel = cscale(A.beta2, v0);
+      vel.x += (1.0 - A.beta2) * met;  // scalar broadcast into the matrix (:325-328)
+      double2 den = csqrt_principal(vel);
+      den.x += A.eps;
+      const double2 dir = cmul(mom, cinv(den));
+      const double2 X = cscale(-lr, dir);
+      S[2 * kMat + sub] = X;
+      S[3 * kMat + sub] = mom;
+      S[4 * kMat + sub] = vel;
+      __syncthreads();
+      double2 a = make_double2(0.0, 0.0);  // X U^H - U X^H (:54)
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        a = cadd(a, cmulc(S[2 * kMat + i * 4 + l], Uk[j * 4 + l]));
+        a = csub(a, cmulc(Uk[i * 4 + l], S[2 * kMat + j * 4 + l]));
+      }
+      const double dg = (i == j) ? 1.0 : 0.0;
+      double2 mm = make_double2(dg - 0.5 * a.x, -0.5 * a.y);
+      S[5 * kMat + sub] = make_double2(dg + 0.5 * a.x, 0.5 * a.y);
+      __syncthreads();
+      double2 y = make_double2(0.0, 0.0);  // (I + a/2) U
+#pragma unroll
+      for (int l = 0; l < 4; ++l) y = cadd(y, cmul(S[5 * kMat + i * 4 + l], Uk[l * 4 + j]));
+      // (I - a/2) Y = (I + a/2) U by Gauss-Jordan; a is skew-Hermitian, so the Hermitian part of
+      // the matrix is the identity and elimination without pivoting is stable.
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        S[6 * kMat + sub] = mm;
+        S[7 * kMat + sub] = y;
+        __syncthreads();
+        const double2 inv = cinv(S[6 * kMat + p * 4 + p]);
+        const double2 mpj = S[6 * kMat + p * 4 + j], ypj = S[7 * kMat + p * 4 + j];
+        if (i == p) {
+          mm = cmul(mpj, inv);
+          y = cmul(ypj, inv);
+        } else {
+          const double2 f = cmul(S[6 * kMat + i * 4 + p], inv);
+          mm = csub(mm, cmul(f, mpj));
+          y = csub(y, cmul(f, ypj));
+        }
+        __syncthreads();
+      }
+      S[8 * kMat + sub] = y;  // the new gate
+      double df = (y.x - u.x) * (y.x - u.x) + (y.y - u.y) * (y.y - u.y);
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) df += shfl_xor_d(df, m);
+      if (act && sub == 0) dnorm[k] = sqrt(df);
+      __syncthreads();
+      if (!A.frozen) {  // vector transport 0.5 (M - U M^H U) of both moments (:344-345)
+        double2 tm = make_double2(0.0, 0.0), tv = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          tm = cadd(tm, cmulc(S[8 * kMat + i * 4 + l], S[3 * kMat + j * 4 + l]));
+          tv = cadd(tv, cmulc(S[8 * kMat + i * 4 + l], S[4 * kMat + j * 4 + l]));
+        }
+        S[0 * kMat + sub] = tm;
+        S[1 * kMat + sub] = tv;
+      }
+      __syncthreads();
+      if (!A.frozen) {
+        double2 mn = mom, vn = vel;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          mn = csub(mn, cmul(S[0 * kMat + i * 4 + l], S[8 * kMat + l * 4 + j]));
+          vn = csub(vn, cmul(S[1 * kMat + i * 4 + l], S[8 * kMat + l * 4 + j]));
+        }
+        if (act) {
+          A.mom[gbase + k * kMat + sub] = cscale(0.5, mn);
+          A.vel[gbase + k * kMat + sub] = cscale(0.5, vn);
+        }
+      }
+      if (act) U[k * kMat + sub] = y;
+      __syncthreads();
+    }
+
+    // ---- bookkeeping of minimize() (:124-147), identical in every thread
+    if (tid == 0) A.hist[inst * (long)A.max_iter + it] = val;
+    ++it;
+    if (val < best_val) {
+      best_val = val;
+      for (int e = tid; e < G * kMat; e += NT) A.best_g[gbase + e] = U[e];
+    }
+    if (val < A.tol) break;
+    double dsum = 0.0;
+    for (int k = 0; k < G; ++k) dsum += dnorm[k];
+    if (dsum / G < A.param_tol) break;
+  }
+  for (int e = tid; e < G * kMat; e += NT) A.final_g[gbase + e] = U[e];
+  if (tid == 0) {
+    A.best_val[inst] = best_val;
+    A.n_iter[inst] = it;
+  }
+}
+
+#define HIP_TRY(x)                                                                        \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess) {                                                               \
+      snprintf(g_err, sizeof g_err, "%s: %s", #x, hipGetErrorString(e_));                 \
+      rc = E_HIP;                                                                         \
+      goto done;                                                                          \
+    }                                                                                     \
+  } while (0)
+
+template <int N, int NT>
+hipError_t launch(const FitArgs& A, int batch, size_t lds, hipStream_t st) {
+  auto fn = reinterpret_cast<const void*>(&k_fit<N, NT>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_fit<N, NT>), dim3((unsigned)batch), dim3(NT), lds, st, A);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mps2qc_last_error(void) { return g_err; }
+
+int mps2qc_brickwork_sites(int n_qubits, int n_layers, int32_t* sites, int cap) {
+  if (n_qubits < 2 || n_layers < 0 || (!sites && cap > 0)) {
+    snprintf(g_err, sizeof g_err, "mps2qc_brickwork_sites: bad argument");
+    return E_INVAL;
+  }
+  int cnt = 0;
+  for (int l = 0; l < n_layers; ++l)
+    for (int par = 0; par < 2; ++par)
+      for (int i = par; i < n_qubits - 1; i += 2) {
+        if (cnt < cap) sites[cnt] = i;
+        ++cnt;
+      }
+  return cnt;
+}
+
+int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int batch,
+                         const double* target, int target_shared, const double* init_gates, double lr,
+                         double beta1, double beta2, double eps, int jit_frozen, int max_iter,
+                         double tol, double param_tol, int use_mfma, double* opt_gates,
+                         double* final_gates, double* loss_history, double* best_val, int32_t* n_iter,
+                         double* last_envs, double* last_overlap, float* kernel_ms) {
+  int rc = E_OK;
+  g_err[0] = 0;
+  if (n < 2 || n > MPS2QC_MAX_QUBITS || G < 1 || batch < 1 || max_iter < 1 || !sites || !target ||
+      !init_gates) {
+    snprintf(g_err, sizeof g_err, "mps2qc_fit_brickwork: bad argument (2 <= n <= %d, G, batch, max_iter >= 1)",
+             MPS2QC_MAX_QUBITS);
+    return E_INVAL;
+  }
+  std::vector<int> lo(G);
+  for (int k = 0; k < G; ++k) {
+    if (sites[k] < 0 || sites[k] > n - 2) {
+      snprintf(g_err, sizeof g_err, "mps2qc_fit_brickwork: gate %d on sites (%d,%d) outside the register", k,
+               sites[k], sites[k] + 1);
+      return E_INVAL;
+    }
+    lo[k] = n - 2 - sites[k];
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device_id < 0 || device_id >= ndev) {
+    snprintf(g_err, sizeof g_err, "mps2qc_fit_brickwork: no usable HIP device (there is no CPU fallback)");
+    return E_NODEV;
+  }
+  // bias-corrected learning rate of every step (stiefel_opt.py:333-335); t = 1 when frozen
+  std::vector<double> lr_t(max_iter);
+  for (int it = 0; it < max_iter; ++it) {
+    const double t = jit_frozen ? 1.0 : (double)(it + 1);
+    lr_t[it] = lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t));
+  }
+
+  const int NT = n <= 8 ? 64 : 256;
+  const size_t dim = (size_t)1 << n;
+  FitArgs A;
+  memset(&A, 0, sizeof A);
+  size_t off = 2 * dim * 16;
+  A.off_u = (int)off, off += (size_t)G * kMat * 16;
+  A.off_e = (int)off, off += (size_t)G * kMat * 16;
+  A.off_red = (int)off, off += (size_t)(NT / 64) * 256 * 8;
+  A.off_sc = (int)off, off += 16 * 8;
+  A.off_dn = (int)off, off += (size_t)((G + 1) & ~1) * 8;
+  A.off_lo = (int)off, off += (size_t)((G + 3) & ~3) * 4;
+  const size_t scratch = (size_t)(NT / 16) * kSlotMats * kMat * 16;
+  if (2 * dim * 16 >= scratch) A.off_scratch = 0;  // overlay on psi / phi, idle during the update
+  else A.off_scratch = (int)off, off += scratch;
+  if (off > (size_t)kLdsLimit) {
+    snprintf(g_err, sizeof g_err, "mps2qc_fit_brickwork: %d gates at %d qubits need %zu B of LDS (limit %d)", G, n,
+             off, kLdsLimit);
+    return E_INVAL;
+  }
+
+  const size_t gsz = (size_t)batch * G * kMat * 16;
+  const size_t tsz = (target_shared ? 1 : (size_t)batch) * dim * 16;
+  int* d_lo = nullptr;
+  double *d_lr = nullptr, *d_hist = nullptr, *d_bv = nullptr;
+  double2 *d_t = nullptr, *d_init = nullptr, *d_fin = nullptr, *d_best = nullptr, *d_m = nullptr, *d_v = nullptr,
+          *d_env = nullptr, *d_ov = nullptr;
+  int* d_ni = nullptr;
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float ms = 0.f;
+
+  HIP_TRY(hipSetDevice(device_id));
+  HIP_TRY(hipStreamCreate(&st));
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipMalloc(&d_lo, G * sizeof(int)));
+  HIP_TRY(hipMalloc(&d_lr, max_iter * sizeof(double)));
+  HIP_TRY(hipMalloc(&d_hist, (size_t)batch * max_iter * sizeof(double)));
+  HIP_TRY(hipMalloc(&d_bv, batch * sizeof(double)));
+  HIP_TRY(hipMalloc(&d_ni, batch * sizeof(int)));
+  HIP_TRY(hipMalloc(&d_t, tsz));
+  HIP_TRY(hipMalloc(&d_init, gsz));
+  HIP_TRY(hipMalloc(&d_fin, gsz));
+  HIP_TRY(hipMalloc(&d_best, gsz));
+  HIP_TRY(hipMalloc(&d_m, gsz));
+  HIP_TRY(hipMalloc(&d_v, gsz));
+  HIP_TRY(hipMalloc(&d_env, gsz));
+  HIP_TRY(hipMalloc(&d_ov, batch * 16));
+  HIP_TRY(hipMemcpyAsync(d_lo, lo.data(), G * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_lr, lr_t.data(), max_iter * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_t, target, tsz, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_init, init_gates, gsz, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)batch * max_iter * sizeof(double), st));
+  HIP_TRY(hipMemcpyAsync(d_best, init_gates, gsz, hipMemcpyHostToDevice, st));
+
+  A.G = G, A.max_iter = max_iter, A.frozen = jit_frozen ? 1 : 0, A.use_mfma = use_mfma ? 1 : 0;
+  A.target_shared = target_shared ? 1 : 0;
+  A.beta1 = beta1, A.beta2 = beta2, A.eps = eps, A.tol = tol, A.param_tol = param_tol;
+  A.lo = d_lo, A.lr_t = d_lr, A.target = d_t, A.init = d_init, A.final_g = d_fin, A.best_g = d_best;
+  A.mom = d_m, A.vel = d_v, A.hist = d_hist, A.best_val = d_bv, A.n_iter = d_ni, A.envs = d_env, A.overlap = d_ov;
+
+  HIP_TRY(hipEventRecord(e0, st));
+  {
+    hipError_t le = hipErrorInvalidValue;
+    switch (n) {
+#define CASE(NN, TT) case NN: le = launch<NN, TT>(A, batch, off, st); break;
+      CASE(2, 64) CASE(3, 64) CASE(4, 64) CASE(5, 64) CASE(6, 64) CASE(7, 64) CASE(8, 64)
+      CASE(9, 256) CASE(10, 256) CASE(11, 256) CASE(12, 256)
+#undef CASE
+    }
+    HIP_TRY(le);
+  }
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (kernel_ms) *kernel_ms = ms;
+  if (opt_gates) HIP_TRY(hipMemcpy(opt_gates, d_best, gsz, hipMemcpyDeviceToHost));
+  if (final_gates) HIP_TRY(hipMemcpy(final_gates, d_fin, gsz, hipMemcpyDeviceToHost));
+  if (loss_history)
+    HIP_TRY(hipMemcpy(loss_history, d_hist, (size_t)batch * max_iter * sizeof(double), hipMemcpyDeviceToHost));
+  if (best_val) HIP_TRY(hipMemcpy(best_val, d_bv, batch * sizeof(double), hipMemcpyDeviceToHost));
+  if (n_iter) HIP_TRY(hipMemcpy(n_iter, d_ni, batch * sizeof(int), hipMemcpyDeviceToHost));
+  if (last_envs) HIP_TRY(hipMemcpy(last_envs, d_env, gsz, hipMemcpyDeviceToHost));
+  if (last_overlap) HIP_TRY(hipMemcpy(last_overlap, d_ov, (size_t)batch * 16, hipMemcpyDeviceToHost));
+
+done:
+  for (void* p : {(void*)d_lo, (void*)d_lr, (void*)d_hist, (void*)d_bv, (void*)d_ni, (void*)d_t, (void*)d_init,
+                  (void*)d_fin, (void*)d_best, (void*)d_m, (void*)d_v, (void*)d_env, (void*)d_ov})
+    (void)hipFree(p);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+"""``mps_to_qc`` (reference: dmrg-to-qc/mps2qc.py:242-339) on the GPU, batched over restarts."""
+from __future__ import annotations
+
+import numpy as np
+
+from .stiefel_opt import BrickworkOverlap, StiefelAdam
+from .tnqc_ansatze import brickwork_ansatz
+
+
+def rand_uni(n, rng=None):
+    """Haar-random n x n unitary (mps2qc.py:17-19 draws scipy.stats.unitary_group)."""
+    rng = np.random.default_rng() if rng is None else rng
+    z = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    q, r = np.linalg.qr(z)
+    return q * (np.diag(r) / np.abs(np.diag(r)))
+
+
+def mps_to_dense(tensors):
+    """Open-boundary MPS with site tensors ``(Dl, 2, Dr)`` -> dense vector, site 0 most
+    significant (the ordering of quimb's ``to_dense``)."""
+    v = np.ones((1, 1), complex)
+    for t in tensors:
+        v = np.einsum("xl,lpr->xpr", v, np.asarray(t, complex)).reshape(-1, t.shape[2])
+    return v.reshape(-1)
+
+
+def mps_to_qc(mps, ansatz=None, optimizer_opts=None, n_restarts=1, rng=None, init_params=None):
+    """Fit a brickwork circuit to ``mps`` (a dense state or a list of site tensors).
+
+    Same options as the reference: ``ansatz = {'structure': 'brickwork', 'num_layers': L}``,
+    ``optimizer_opts = {'method': StiefelAdam(...), 'max_iter': 2000, 'tol': 1e-6,
+    'param_tol': 1e-6}`` (:299-303).  Where the reference runs one fit from one random start,
+    ``n_restarts`` starts run side by side in one launch and the best one is returned.
+    Returns ``(gates, loss_history, opt_params)`` of the best restart: ``gates`` the list of
+    4x4 unitaries in application order (the tensors the reference writes into ``qc_mps``),
+    ``opt_params`` the dict ``{k: gate_k}``."""
+    ansatz = {"structure": "brickwork", "num_layers": 2} if ansatz is None else ansatz
+    optimizer_opts = {} if optimizer_opts is None else optimizer_opts
+    target = np.asarray(mps, complex) if not isinstance(mps, (list, tuple)) else mps_to_dense(mps)
+    n = int(np.log2(target.shape[-1]))
+    if ansatz.get("structure") != "brickwork":
+        raise ValueError("Unknown ansatz type. Only 'brickwork' is supported.")
+    sites, G = brickwork_ansatz(n, ansatz.get("num_layers"))
+    opt = optimizer_opts.get("method") or StiefelAdam(3e-3, 0.9, 0.999, 1e-8)
+    if init_params is None:
+        init_params = np.array([[rand_uni(4, rng) for _ in range(G)] for _ in range(n_restarts)])
+    opt.init(init_params)
+    opt.minimize(BrickworkOverlap(n, sites, target), init_params,
+                 max_iter=optimizer_opts.get("max_iter", 2000), tol=optimizer_opts.get("tol", 1e-6),
+                 param_tol=optimizer_opts.get("param_tol", 1e-6))
+    best = int(np.argmin(opt.best_val)) if np.ndim(opt.best_val) else None
+    gates = opt.opt_params if best is None else opt.opt_params[best]
+    hist = opt.loss_history if best is None else opt.loss_history[best]
+    return [g for g in gates], hist, {k: g for k, g in enumerate(gates)}

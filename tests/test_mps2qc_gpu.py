@@ -1,0 +1,145 @@
+"""GPU parity of the MPS -> PQC fit (libmps2qc_hip.so, through its C ABI) against the numpy
+restatement of dmrg-to-qc/stiefel_opt.py + mps2qc.py (oracle/stiefel_oracle.py).
+
+Tolerances: environments / overlaps of one step <= 1e-12, gates after one update <= 1e-12, loss
+histories over 60 steps <= 1e-10, gates after 60 steps <= 1e-9 (rounding differences of the
+FMA-contracted device arithmetic grow slowly along the trajectory)."""
+import numpy as np
+import pytest
+
+import stiefel_oracle as so
+from helpers import load_case, oracle_init_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n, layers, rng, batch=2, representable=True):
+    from tensorrl_qas_amd import dmrg_to_qc as dq
+    sites, G = dq.brickwork_ansatz(n, layers)
+    assert list(sites) == so.brickwork_pairs(n, layers)
+    if representable:
+        tg = [so.circuit_state(n, sites, so.random_unitaries(G, rng)) for _ in range(batch)]
+    else:
+        tg = []
+        for _ in range(batch):
+            v = rng.normal(size=1 << n) + 1j * rng.normal(size=1 << n)
+            tg.append(v / np.linalg.norm(v))
+    init = np.array([so.random_unitaries(G, rng) for _ in range(batch)])
+    return sites, G, np.array(tg), init
+
+
+@pytest.mark.parametrize("mfma", [True, False])
+@pytest.mark.parametrize("n,layers", [(2, 1), (3, 2), (4, 1), (5, 2), (6, 1), (7, 3), (8, 1), (9, 2), (10, 1),
+                                      (11, 2), (12, 1), (12, 4)])
+def test_one_step_matches_oracle(n, layers, mfma):
+    from tensorrl_qas_amd import dmrg_to_qc as dq
+    rng = np.random.default_rng(100 * n + layers)
+    sites, G, tg, init = _problem(n, layers, rng, representable=(n % 2 == 0))
+    for frozen in (False, True):
+        opt = dq.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=frozen, use_mfma=mfma)
+        opt.init(init)
+        opt.minimize(dq.BrickworkOverlap(n, sites, tg), init, max_iter=1, tol=1e-30, param_tol=0.0)
+        for b in range(len(init)):
+            o, envs = so.overlap_and_envs(n, list(sites), list(init[b]), tg[b])
+            assert abs(opt.last_overlap[b] - o) < 1e-12
+            assert np.max(np.abs(opt.last_envs[b] - np.array(envs))) < 1e-12
+            ref = so.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=frozen)
+            ref.init(init[b])
+            bv, bp, hist, fin = ref.minimize(n, list(sites), tg[b], init[b], max_iter=1, tol=1e-30, param_tol=0.0)
+            assert np.max(np.abs(opt.final_params[b] - np.array(fin))) < 1e-12
+            assert np.max(np.abs(opt.opt_params[b] - np.array(bp))) < 1e-12
+            assert abs(opt.best_val[b] - bv) < 1e-12 and opt.n_iter[b] == 1
+            assert abs(opt.loss_history[b][0] - hist[0]) < 1e-12
+
+
+@pytest.mark.parametrize("frozen", [False, True])
+@pytest.mark.parametrize("n,layers", [(4, 2), (6, 1), (9, 1), (12, 1)])
+def test_trajectory_matches_oracle(n, layers, frozen):
+    from tensorrl_qas_amd import dmrg_to_qc as dq
+    rng = np.random.default_rng(7 * n + layers)
+    sites, G, tg, init = _problem(n, layers, rng, batch=2)
+    steps = 60 if n < 12 else 25
+    opt = dq.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=frozen)
+    opt.init(init)
+    opt.minimize(dq.BrickworkOverlap(n, sites, tg), init, max_iter=steps, tol=1e-12, param_tol=1e-9)
+    for b in range(2):
+        ref = so.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=frozen)
+        ref.init(init[b])
+        bv, bp, hist, fin = ref.minimize(n, list(sites), tg[b], init[b], max_iter=steps, tol=1e-12, param_tol=1e-9)
+        assert opt.n_iter[b] == len(hist)
+        assert np.max(np.abs(np.array(opt.loss_history[b]) - np.array(hist))) < 1e-10
+        assert np.max(np.abs(opt.final_params[b] - np.array(fin))) < 1e-9
+        assert np.max(np.abs(opt.opt_params[b] - np.array(bp))) < 1e-9
+        assert abs(opt.best_val[b] - bv) < 1e-10
+        for g in opt.final_params[b]:
+            assert np.max(np.abs(g @ g.conj().T - np.eye(4))) < 1e-12
+        assert hist[-1] < hist[0]
+
+
+def test_large_learning_rate_and_termination():
+    """A big step (lr = 0.3: I - a/2 far from the identity, complex velocities after the
+    transport) and both stopping rules of minimize()."""
+    from tensorrl_qas_amd import dmrg_to_qc as dq
+    rng = np.random.default_rng(5)
+    n, layers = 5, 2
+    sites, G, tg, init = _problem(n, layers, rng, batch=3)
+    opt = dq.StiefelAdam(0.3, 0.9, 0.99, 1e-10)
+    opt.init(init)
+    opt.minimize(dq.BrickworkOverlap(n, sites, tg), init, max_iter=8, tol=1e-12, param_tol=1e-9)
+    for b in range(3):
+        ref = so.StiefelAdam(0.3, 0.9, 0.99, 1e-10)
+        ref.init(init[b])
+        bv, bp, hist, fin = ref.minimize(n, list(sites), tg[b], init[b], max_iter=8, tol=1e-12, param_tol=1e-9)
+        assert np.max(np.abs(np.array(opt.loss_history[b]) - np.array(hist))) < 1e-9
+        assert np.max(np.abs(opt.final_params[b] - np.array(fin))) < 1e-8
+    # tol: start at the exact solution -> loss ~ 1e-16 < tol after one step
+    exact = np.array([so.random_unitaries(G, rng)])
+    t = so.circuit_state(n, sites, exact[0])
+    opt.minimize(dq.BrickworkOverlap(n, sites, t), exact, max_iter=50, tol=1e-8, param_tol=0.0)
+    assert opt.n_iter[0] == 1 and opt.best_val[0] < 1e-12
+    # param_tol: with a vanishing learning rate the gates do not move
+    opt2 = dq.StiefelAdam(1e-12, 0.9, 0.999, 1e-8)
+    opt2.minimize(dq.BrickworkOverlap(n, sites, tg), init, max_iter=50, tol=1e-30, param_tol=1e-6)
+    assert list(opt2.n_iter) == [1, 1, 1]
+
+
+def test_shared_target_many_restarts_fit_golden_init_state():
+    """End to end: the reference's shipped H2O-8q init circuit (21 cx + 129 rotations = 7 SU(4)
+    blocks, one brickwork layer) is exactly representable; 64 restarts fitted in one launch."""
+    from tensorrl_qas_amd import dmrg_to_qc as dq
+    psi = oracle_init_state(load_case("H2O_8q"))
+    n = 8
+    rng = np.random.default_rng(0)
+    opt = dq.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=True)
+    gates, hist, params = dq.mps_to_qc(psi, {"structure": "brickwork", "num_layers": 1},
+                                       {"method": opt, "max_iter": 3000, "tol": 1e-8}, n_restarts=64, rng=rng)
+    sites, G = dq.brickwork_ansatz(n, 1)
+    assert G == 7 and len(gates) == 7
+    best = float(np.min(opt.best_val))
+    assert best < 5e-3, best
+    # the loss the kernel reports is the loss of the gates one step earlier; the returned
+    # gates are at least as good up to one step of size lr
+    assert so.loss(n, list(sites), gates, psi) < best + 1e-2
+    assert hist[-1] <= hist[0]
+    assert all(np.max(np.abs(g @ g.conj().T - np.eye(4))) < 1e-10 for g in gates)
+
+
+def test_mfma_and_valu_agree_and_errors():
+    from tensorrl_qas_amd import dmrg_to_qc as dq, VQEError
+    rng = np.random.default_rng(11)
+    n, layers = 10, 2
+    sites, G, tg, init = _problem(n, layers, rng, batch=4, representable=False)
+    res = []
+    for mfma in (True, False):
+        opt = dq.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, use_mfma=mfma)
+        opt.minimize(dq.BrickworkOverlap(n, sites, tg), init, max_iter=40, tol=1e-12, param_tol=1e-9)
+        res.append((np.array(opt.loss_history), opt.final_params.copy()))
+    assert np.max(np.abs(res[0][0] - res[1][0])) < 1e-11
+    assert np.max(np.abs(res[0][1] - res[1][1])) < 1e-10
+    with pytest.raises(VQEError):
+        dq.StiefelAdam().minimize(dq.BrickworkOverlap(13, np.zeros(1, np.int32), np.zeros(1 << 13, complex)),
+                                  np.eye(4)[None, None], max_iter=1)
+    s12, G12 = dq.brickwork_ansatz(12, 6)  # 66 gates do not fit beside two 64-KiB states
+    with pytest.raises(VQEError):
+        dq.StiefelAdam().minimize(dq.BrickworkOverlap(12, s12, np.ones(1 << 12, complex) / 64),
+                                  np.tile(np.eye(4), (1, G12, 1, 1)), max_iter=1)

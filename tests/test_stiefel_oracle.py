@@ -1,0 +1,98 @@
+"""CPU: properties that pin the numpy restatement of the MPS -> PQC fit (the reference holds no
+tests or recorded outputs for it: parity unpinned), and the C ABI of libmps2qc_hip.so."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+import stiefel_oracle as so
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tensorrl_qas_amd import _lib
+    text = open(os.path.join(ROOT, "include", "mps2qc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mps2qc_[a-z_0-9]+)\s*\(", text)))
+    lib = C.CDLL(_lib.MPS2QC_LIB_PATH)
+    assert len(names) == 3
+    for name in names:
+        assert hasattr(lib, name)
+    assert sorted(_lib.MPS2QC_SIGNATURES) == names
+
+
+def test_brickwork_order_and_no_gpu_failure():
+    import torch
+    from tensorrl_qas_amd import dmrg_to_qc as dq, VQEError
+    import pytest
+    # tnqc_ansatze.py:85-95 for 6 qubits, 2 layers: G1..G3 on (0,1),(2,3),(4,5), G4, G5 on (1,2),(3,4)
+    sites, cnt = dq.brickwork_ansatz(6, 2)
+    assert list(sites) == [0, 2, 4, 1, 3, 0, 2, 4, 1, 3] == so.brickwork_pairs(6, 2) and cnt == 10
+    assert dq.brickwork_ansatz(5, 1)[1] == 4 and dq.brickwork_ansatz(2, 3)[1] == 3
+    assert dq.tnqc_ansatze.qiskit_gate_qargs([0, 2]) == [[1, 0], [3, 2]]
+    if not torch.cuda.is_available():
+        with pytest.raises(VQEError):
+            dq.StiefelAdam().minimize(dq.BrickworkOverlap(2, np.zeros(1, np.int32), np.array([1, 0, 0, 0j])),
+                                      np.eye(4)[None, None], max_iter=1)
+
+
+def test_gradient_matches_finite_differences():
+    rng = np.random.default_rng(0)
+    n = 5
+    sites = so.brickwork_pairs(n, 2)
+    G = len(sites)
+    target = so.circuit_state(n, sites, so.random_unitaries(G, rng))
+    g0 = so.random_unitaries(G, rng)
+    o, envs = so.overlap_and_envs(n, sites, g0, target)
+    for k in range(G):  # the overlap is linear in every gate
+        assert abs(np.sum(g0[k] * envs[k]) - o) < 1e-13
+    gr = so.euclid_grads(o, envs)
+    h = 1e-6
+    for k, a, b in [(3, 0, 1), (5, 3, 2), (G - 1, 1, 0), (0, 2, 0)]:
+        for d in (1.0, 1j):
+            gp = [x.copy() for x in g0]
+            gm = [x.copy() for x in g0]
+            gp[k][a, b] += h * d
+            gm[k][a, b] -= h * d
+            fd = (so.loss(n, sites, gp, target) - so.loss(n, sites, gm, target)) / (2 * h)
+            an = gr[k][a, b].real if d == 1.0 else gr[k][a, b].imag
+            assert abs(fd - an) < 1e-8
+
+
+def test_update_stays_unitary_and_descends():
+    rng = np.random.default_rng(1)
+    n = 6
+    sites = so.brickwork_pairs(n, 1)
+    G = len(sites)
+    target = so.circuit_state(n, sites, so.random_unitaries(G, rng))
+    g0 = so.random_unitaries(G, rng)
+    for frozen in (False, True):
+        opt = so.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=frozen)
+        opt.init(g0)
+        bv, bp, hist, fin = opt.minimize(n, sites, target, g0, max_iter=150, tol=1e-8)
+        assert len(hist) == 150 and hist[-1] < hist[0] and bv == min(hist)
+        assert max(np.abs(x @ x.conj().T - np.eye(4)).max() for x in fin) < 1e-12
+    # first step of the frozen variant: X = -lr rg/|rg| and a = X U^H - U X^H = 2 X U^H, so every gate
+    # moves by 2 lr in Frobenius norm whatever the size of the gradient (normalised step)
+    opt = so.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=True)
+    opt.init(g0)
+    _, _, _, p1 = opt.minimize(n, sites, target, g0, max_iter=1, tol=0.0, param_tol=0.0)
+    d = [np.linalg.norm(a - b) for a, b in zip(p1, g0)]
+    assert np.allclose(d, 6e-3, rtol=1e-3)
+
+
+def test_mps_to_dense_and_cayley_identities():
+    rng = np.random.default_rng(2)
+    ts = [rng.normal(size=(1, 2, 2)), rng.normal(size=(2, 2, 2)), rng.normal(size=(2, 2, 1))]
+    v = so.mps_to_dense(ts)
+    assert v.shape == (8,)
+    assert np.isclose(v[0b101], (ts[0][0, 1] @ ts[1][:, 0] @ ts[2][:, 1])[0])
+    from tensorrl_qas_amd.dmrg_to_qc import mps2qc, closest_unitary
+    assert np.allclose(mps2qc.mps_to_dense(ts), v)
+    u = so.random_unitaries(1, rng)[0]
+    x = rng.normal(size=(4, 4)) + 1j * rng.normal(size=(4, 4))
+    w = so.cayley_retraction(0.1 * so.riemannian_grad(x, u), u)
+    assert np.max(np.abs(w @ w.conj().T - np.eye(4))) < 1e-13
+    assert np.max(np.abs(closest_unitary(u + 1e-9 * x) - u)) < 1e-8
