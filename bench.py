@@ -168,6 +168,52 @@ def episode_aux(tq, torch, dev, num_envs, max_steps):
                 [int((e.state[:, 12:15] == 1).sum()) for e in envs]))}
 
 
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64, vector = matrix rate (half of the guide's 157.3 TF FP32 vector figure)
+
+
+def mps2qc_aux(tq, dev, with_cpu):
+    """Offline MPS -> PQC fit (reference dmrg-to-qc/mps2qc.py + stiefel_opt.py): 1024
+    random restarts of a 12-qubit one-layer brickwork (11 SU(4) gates) fitted to one random target for 200
+    Stiefel-Adam steps in ONE launch of k_fit<12,512>.  Algorithmic flops per optimiser step:
+    G forward + 2G backward gate sweeps + G environments, each 2^n * 32 flop (16 complex MACs per 4 amplitudes)."""
+    from tensorrl_qas_amd import dmrg_to_qc as dq
+    n, layers, B, iters = 12, 1, 1024, 200
+    rng = np.random.default_rng(1212)
+    sites, G = dq.brickwork_ansatz(n, layers)
+    v = rng.normal(size=1 << n) + 1j * rng.normal(size=1 << n)
+    target = v / np.linalg.norm(v)
+    init = np.array([[dq.rand_uni(4, rng) for _ in range(G)] for _ in range(B)])
+    opt = dq.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=True, device_id=dev)
+    prob = dq.BrickworkOverlap(n, sites, target)
+    opt.minimize(prob, init, max_iter=iters, tol=0.0, param_tol=0.0)       # warm-up launch
+    opt.minimize(prob, init, max_iter=iters, tol=0.0, param_tol=0.0)
+    steps = int(np.sum(opt.n_iter))
+    flop = steps * 4 * G * (1 << n) * 32
+    tf = flop / (opt.kernel_ms * 1e-3) / 1e12
+    out = {"workload": f"brickwork_fit_{n}q_{layers}layer_G{G}_B{B}_iters{iters}_random_target",
+           "optimiser_steps_per_s": steps / (opt.kernel_ms * 1e-3), "fits_per_s": B / (opt.kernel_ms * 1e-3),
+           "kernel": "k_fit<12,512>", "kernel_ms": opt.kernel_ms, "mean_final_loss": float(np.mean(
+               [h[-1] for h in opt.loss_history])), "dtype": "f64",
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tf / FP64_PEAK_TFLOPS, "traffic": None,
+                        "algorithmic_flop_per_step": 4 * G * (1 << n) * 32,
+                        "note": "environments on v_mfma_f64_16x16x4_f64, gate sweeps on FP64 vector FMAs; "
+                                "both pipes peak at the same 78.6 TFLOP/s on MI355X; states LDS-resident"}}
+    if with_cpu:      # the numpy restatement (oracle/stiefel_oracle.py) on one fit, a few steps
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import stiefel_oracle as so
+        ref = so.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=True)
+        ref.init(init[0])
+        t0 = time.perf_counter()
+        _, _, hist, _ = ref.minimize(n, list(sites), target, init[0], max_iter=40, tol=0.0, param_tol=0.0)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": len(hist) / dt, "unit": "optimiser steps/s", "cores": 1, "kind": "port",
+                               "sample": "40 steps of one fit, numpy restatement (the reference runs jax + quimb)",
+                               "max_abs_loss_diff_vs_gpu": float(np.max(np.abs(
+                                   np.array(hist) - np.array(opt.loss_history[0][:len(hist)]))))}
+    return out
+
+
 def heis20_aux(tq, torch, dist, rank, world, dev, steps):
     """20-qubit Heisenberg <H>: every rank applies the same circuits, evaluates its share of
     the X-mask groups, one all-reduce (RCCL) sums the partial energies.  Strong scaling of
@@ -233,6 +279,7 @@ def main():
     ap.add_argument("--maxfun", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-heis20", action="store_true")
+    ap.add_argument("--no-mps2qc", action="store_true")
     ap.add_argument("--episode", action="store_true", help="also run the LIH12q fixed config through "
                     "VecCircuitEnv (adds launches of the same kernel with other sizes: keep it out of profiled runs)")
     ap.add_argument("--episode-envs", type=int, default=1024)
@@ -368,6 +415,8 @@ def main():
                 out["roofline"]["issue"] = {k: st[k] for k in st if k not in ("workload", "kernel")}
         if heis is not None:
             out["heis20"] = heis
+        if not args.no_mps2qc:
+            out["mps2qc"] = mps2qc_aux(tq, local, not args.no_cpu_baseline and world == 1)
         if not args.no_cpu_baseline and world == 1:      # timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(tq, ham, psi0, batch, G, args.cpu_steps, args.maxfun)
         print(json.dumps(out), flush=True)

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -57,6 +58,11 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 __device__ __forceinline__ double2 cmulc(double2 a, double2 b) {  // a * conj(b)
   return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
+// s + a * b as four fused multiply-adds
+__device__ __forceinline__ double2 cmac(double2 s, double2 a, double2 b) {
+  double x = __builtin_fma(a.x, b.x, s.x), y = __builtin_fma(a.x, b.y, s.y);
+  return make_double2(__builtin_fma(-a.y, b.y, x), __builtin_fma(a.y, b.x, y));
+}
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double2 cscale(double s, double2 a) { return make_double2(s * a.x, s * a.y); }
@@ -74,6 +80,12 @@ __device__ __forceinline__ double2 csqrt_principal(double2 z) {
 }
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
 
+// Physical LDS slot of amplitude idx.  A thread reads the four amplitudes idx | b << lo of its
+// 4-vector with ds_read_b128; for lo < 4 sixteen neighbouring lanes would otherwise meet in 4 (lo
+// <= 2) or 8 of the 16 16-byte bank groups.  XORing bits 0/2 with bit 4 and bits 1/3 with bit 5
+// makes every aligned group of 16 lanes cover all 16 bank groups for every lo.
+__device__ __forceinline__ int sw(int idx) { return idx ^ (((idx >> 4) & 3) * 5); }
+
 // 4x4 gate (or its adjoint) from LDS into registers: wave-uniform broadcast reads.
 __device__ __forceinline__ void load_gate(double2 (&m)[16], const double2* M, bool dagger) {
 #pragma unroll
@@ -86,26 +98,95 @@ __device__ __forceinline__ void load_gate(double2 (&m)[16], const double2* M, bo
     }
 }
 
-// st <- m on the qubit pair whose low bit is `lo`; every thread owns whole 4-vectors.
-template <int N, int NT>
-__device__ __forceinline__ void apply_gate(double2* st, const double2 (&m)[16], int lo, int tid) {
-  constexpr int R = 1 << (N - 2);
-  const int lmask = (1 << lo) - 1;
-  for (int r = tid; r < R; r += NT) {
-    const int base = ((r >> lo) << (lo + 2)) | (r & lmask);
-    double2 v[4], w[4];
+// v <- m v for the 4-vectors already in registers
+template <int IT>
+__device__ __forceinline__ void mat4(const double2 (&m)[16], double2 (&v)[IT][4]) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) v[b] = st[base | (b << lo)];
+  for (int t = 0; t < IT; ++t) {
+    double2 w[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      double2 s = cmul(m[a * 4], v[0]);
+      double2 s = cmul(m[a * 4], v[t][0]);
 #pragma unroll
-      for (int b = 1; b < 4; ++b) s = cadd(s, cmul(m[a * 4 + b], v[b]));
+      for (int b = 1; b < 4; ++b) s = cmac(s, m[a * 4 + b], v[t][b]);
       w[a] = s;
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a) st[base | (a << lo)] = w[a];
+    for (int a = 0; a < 4; ++a) v[t][a] = w[a];
   }
+}
+
+// st <- m on the qubit pair whose low bit is `lo`; every thread owns whole 4-vectors.  The trip
+// count is a compile-time constant and all LDS reads are issued before the arithmetic.
+template <int N, int NT>
+__device__ __forceinline__ void apply_gate(double2* st, const double2 (&m)[16], int lo, int tid) {
+  constexpr int R = 1 << (N - 2);
+  constexpr int IT = R >= NT ? R / NT : 1;
+  const int lmask = (1 << lo) - 1;
+  double2 v[IT][4];
+  int base[IT];
+#pragma unroll
+  for (int t = 0; t < IT; ++t) {
+    const int r = tid + t * NT;
+    base[t] = ((r >> lo) << (lo + 2)) | (r & lmask);
+    if (R >= NT || r < R) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v[t][b] = st[sw(base[t] | (b << lo))];
+    }
+  }
+  mat4<IT>(m, v);
+#pragma unroll
+  for (int t = 0; t < IT; ++t)
+    if (R >= NT || tid + t * NT < R) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) st[sw(base[t] | (a << lo))] = v[t][a];
+    }
+}
+
+// Two independent sweeps (phi <- m1 phi, psi <- m2 psi) in one barrier interval, their LDS reads
+// in flight together.
+template <int N, int NT>
+__device__ __forceinline__ void apply_two(double2* s1, const double2* M1, int lo1, double2* s2, const double2* M2,
+                                          int lo2, int tid) {
+  constexpr int R = 1 << (N - 2);
+  constexpr int IT = R >= NT ? R / NT : 1;
+  const int lm1 = (1 << lo1) - 1, lm2 = (1 << lo2) - 1;
+  double2 v1[IT][4], v2[IT][4];
+  int b1[IT], b2[IT];
+#pragma unroll
+  for (int t = 0; t < IT; ++t) {
+    const int r = tid + t * NT;
+    b1[t] = ((r >> lo1) << (lo1 + 2)) | (r & lm1);
+    b2[t] = ((r >> lo2) << (lo2 + 2)) | (r & lm2);
+    if (R >= NT || r < R) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v1[t][b] = s1[sw(b1[t] | (b << lo1))];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v2[t][b] = s2[sw(b2[t] | (b << lo2))];
+    }
+  }
+  {
+    double2 m[16];
+    load_gate(m, M1, true);
+    mat4<IT>(m, v1);
+  }
+#pragma unroll
+  for (int t = 0; t < IT; ++t)
+    if (R >= NT || tid + t * NT < R) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) s1[sw(b1[t] | (a << lo1))] = v1[t][a];
+    }
+  {
+    double2 m[16];
+    load_gate(m, M2, true);
+    mat4<IT>(m, v2);
+  }
+#pragma unroll
+  for (int t = 0; t < IT; ++t)
+    if (R >= NT || tid + t * NT < R) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) s2[sw(b2[t] | (a << lo2))] = v2[t][a];
+    }
 }
 
 // Environment partials on the matrix cores.  One v_mfma_f64_16x16x4_f64 consumes 8 values of
@@ -122,36 +203,51 @@ __device__ __forceinline__ void env_mfma(const double2* phi, const double2* psi,
   const int i = lane & 15, k = lane >> 4;
   const int s = i >> 3, c = (i >> 2) & 1, a = i & 3;
   const int lmask = (1 << lo) - 1;
-  d4 acc = {0.0, 0.0, 0.0, 0.0};
-  for (int ch = wave; ch < CH; ch += NW) {
-    const int r = ch * 8 + s * 4 + k;
-    double av = 0.0, bv = 0.0;
-    if (R >= 8 || r < R) {
-      const int idx = ((r >> lo) << (lo + 2)) | (a << lo) | (r & lmask);
-      av = reinterpret_cast<const double*>(phi)[2 * idx + c];
-      bv = reinterpret_cast<const double*>(psi)[2 * idx + c];
-    }
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-  }
+  // compile-time trip count: all operand reads of the wave are issued before the first MFMA
+  // and two accumulators break the dependency chain
+  constexpr int TR = (CH + NW - 1) / NW;
+  double av[TR], bv[TR];
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) red[(wave * 4 + reg) * 64 + lane] = acc[reg];
+  for (int t = 0; t < TR; ++t) {
+    const int r = (wave + t * NW) * 8 + s * 4 + k;
+    av[t] = 0.0, bv[t] = 0.0;
+    if ((R >= 8 && CH % NW == 0) || r < R) {
+      const int idx = sw(((r >> lo) << (lo + 2)) | (a << lo) | (r & lmask));
+      av[t] = reinterpret_cast<const double*>(phi)[2 * idx + c];
+      bv[t] = reinterpret_cast<const double*>(psi)[2 * idx + c];
+    }
+  }
+  d4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < TR; ++t) {
+    if (t & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc2, 0, 0, 0);
+    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc, 0, 0, 0);
+  }
+  if (TR > 1) acc += acc2;
+  // fold the two r-slices (columns 8..15 hold slice 1, in registers 2 and 3) and keep the 64
+  // meaningful sums of the wave: red[wave][c][a][c'][b]
+  const double x0 = acc[0] + shfl_xor_d(acc[2], 8);
+  const double x1 = acc[1] + shfl_xor_d(acc[3], 8);
+  if ((lane & 8) == 0) {
+    const int cl = (lane >> 4) * 8 + (lane & 7);
+    red[wave * 64 + cl] = x0;
+    red[wave * 64 + 32 + cl] = x1;
+  }
 }
 
-// E[a][b] from the MFMA partials: M_cc'[a][b] sits at reg = 2 s + c, lane = 16 a + 8 s + 4 c' + b.
+// E[a][b] = (M_00 + M_11) + i (M_01 - M_10) with M_cc'[a][b] = sum_r phi_c[a,r] psi_c'[b,r].
 template <int NT>
 __device__ __forceinline__ double2 env_mfma_combine(const double* red, int t) {
   constexpr int NW = NT / 64;
   const int a = t >> 2, b = t & 3;
   double m00 = 0, m01 = 0, m10 = 0, m11 = 0;
-  for (int w = 0; w < NW; ++w)
-    for (int s = 0; s < 2; ++s) {
-      const double* p = red + w * 256;
-      const int ln = a * 16 + s * 8 + b;
-      m00 += p[(2 * s) * 64 + ln];
-      m01 += p[(2 * s) * 64 + ln + 4];
-      m10 += p[(2 * s + 1) * 64 + ln];
-      m11 += p[(2 * s + 1) * 64 + ln + 4];
-    }
+  for (int w = 0; w < NW; ++w) {
+    const double* p = red + w * 64 + a * 8 + b;
+    m00 += p[0];
+    m01 += p[4];
+    m10 += p[32];
+    m11 += p[36];
+  }
   return make_double2(m00 + m11, m01 - m10);
 }
 
@@ -170,8 +266,8 @@ __device__ __forceinline__ void env_valu(const double2* phi, const double2* psi,
     double2 f[4], p[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      f[b] = phi[base | (b << lo)];
-      p[b] = psi[base | (b << lo)];
+      f[b] = phi[sw(base | (b << lo))];
+      p[b] = psi[sw(base | (b << lo))];
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -208,7 +304,7 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int DIM = 1 << N;
   constexpr int NW = NT / 64;
-  constexpr int SLOTS = NT / 16;
+  constexpr int SLOTS = NT / 16 < 16 ? NT / 16 : 16;  // 16-lane groups that run the update
   double2* psi = reinterpret_cast<double2*>(smem);
   double2* phi = psi + DIM;
   double2* U = reinterpret_cast<double2*>(smem + A.off_u);
@@ -236,10 +332,16 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
   __syncthreads();
 
   double best_val = 10000.0;  // stiefel_opt.py:122
+#ifdef MPS2QC_STAMPS
+  long long st_c[5] = {0, 0, 0, 0, 0}, st_t = clock64(), st_n;
+#define STAMP(i) st_n = clock64(), st_c[i] += st_n - st_t, st_t = st_n
+#else
+#define STAMP(i)
+#endif
   int it = 0;
   for (; it < A.max_iter;) {
     // ---- forward
-    for (int i = tid; i < DIM; i += NT) psi[i] = make_double2(i == 0 ? 1.0 : 0.0, 0.0);
+    for (int i = tid; i < DIM; i += NT) psi[i] = make_double2(i == 0 ? 1.0 : 0.0, 0.0);  // sw(0) = 0
     __syncthreads();
     for (int k = 0; k < G; ++k) {
       double2 m[16];
@@ -247,13 +349,14 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
       apply_gate<N, NT>(psi, m, lo_s[k], tid);
       __syncthreads();
     }
+    STAMP(0);
     // ---- overlap o = <t|psi>, phi <- t
     {
       double2 part = make_double2(0.0, 0.0);
       for (int i = tid; i < DIM; i += NT) {
         const double2 t = tgt[i];
-        phi[i] = t;
-        part = cadd(part, cmulc(psi[i], t));
+        phi[sw(i)] = t;
+        part = cadd(part, cmulc(psi[sw(i)], t));
       }
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) {
@@ -278,21 +381,28 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
     const double val = 1.0 - abso;
     const double2 ph = make_double2(o.x / abso, o.y / abso);
 
+    STAMP(1);
     // ---- backward: environments
     for (int k = G - 1; k >= 0; --k) {
       if (A.use_mfma) env_mfma<N, NT>(phi, psi, lo_s[k], red, tid);
       else env_valu<N, NT>(phi, psi, lo_s[k], red, tid);
       __syncthreads();
+      STAMP(2);
       if (tid < 16)
         E[k * kMat + tid] = A.use_mfma ? env_mfma_combine<NT>(red, tid) : env_valu_combine<NT>(red, tid);
       if (k > 0) {  // nothing reads phi_0 / psi_{-1}
-        double2 m[16];
-        load_gate(m, U + k * kMat, true);
-        apply_gate<N, NT>(phi, m, lo_s[k], tid);
-        load_gate(m, U + (k - 1) * kMat, true);
-        apply_gate<N, NT>(psi, m, lo_s[k - 1], tid);
+        if constexpr ((1 << (N - 2)) <= NT) {
+          apply_two<N, NT>(phi, U + k * kMat, lo_s[k], psi, U + (k - 1) * kMat, lo_s[k - 1], tid);
+        } else {  // two 4-vectors per thread and sweep: one sweep at a time keeps it in registers
+          double2 m[16];
+          load_gate(m, U + k * kMat, true);
+          apply_gate<N, NT>(phi, m, lo_s[k], tid);
+          load_gate(m, U + (k - 1) * kMat, true);
+          apply_gate<N, NT>(psi, m, lo_s[k - 1], tid);
+        }
       }
       __syncthreads();
+      STAMP(3);
     }
     if (A.envs)
       for (int e = tid; e < G * kMat; e += NT) A.envs[gbase + e] = E[e];
@@ -300,25 +410,26 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
 
     // ---- StiefelAdam.update, 16 lanes per gate; scratch overlays the idle state vectors
     const double lr = A.lr_t[it];
-    const int sub = tid & 15, slot = tid >> 4;
+    const int sub = tid & 15, slot = (tid >> 4) & (SLOTS - 1);
+    const bool upd = tid < SLOTS * 16;  // the other waves only keep the barriers company
     const int i = sub >> 2, j = sub & 3;
     double2* S = scratch + slot * (kSlotMats * kMat);
     __syncthreads();
     for (int chunk = 0; chunk * SLOTS < G; ++chunk) {
       const int k = chunk * SLOTS + slot;
-      const bool act = k < G;
+      const bool act = upd && k < G;
       const int kk = act ? k : 0;
       const double2* Uk = U + kk * kMat;
       const double2 u = Uk[sub];
       const double2 Ee = E[kk * kMat + sub];
       // Euclidean gradient handed to update(): -(o/|o|) conj(E)
       const double2 g = cmul(make_double2(-ph.x, -ph.y), make_double2(Ee.x, -Ee.y));
-      S[0 * kMat + sub] = g;
+      if (upd) S[0 * kMat + sub] = g;
       __syncthreads();
       double2 t1 = make_double2(0.0, 0.0);  // U G^H
 #pragma unroll
       for (int l = 0; l < 4; ++l) t1 = cadd(t1, cmulc(Uk[i * 4 + l], S[0 * kMat + j * 4 + l]));
-      S[1 * kMat + sub] = t1;
+      if (upd) S[1 * kMat + sub] = t1;
       __syncthreads();
       double2 rg = g;  // riemannian gradient G - U G^H U (:36-42)
 #pragma unroll
@@ -338,9 +449,9 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
       den.x += A.eps;
       const double2 dir = cmul(mom, cinv(den));
       const double2 X = cscale(-lr, dir);
-      S[2 * kMat + sub] = X;
-      S[3 * kMat + sub] = mom;
-      S[4 * kMat + sub] = vel;
+      if (upd) S[2 * kMat + sub] = X;
+      if (upd) S[3 * kMat + sub] = mom;
+      if (upd) S[4 * kMat + sub] = vel;
       __syncthreads();
       double2 a = make_double2(0.0, 0.0);  // X U^H - U X^H (:54)
 #pragma unroll
@@ -350,7 +461,7 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
       }
       const double dg = (i == j) ? 1.0 : 0.0;
       double2 mm = make_double2(dg - 0.5 * a.x, -0.5 * a.y);
-      S[5 * kMat + sub] = make_double2(dg + 0.5 * a.x, 0.5 * a.y);
+      if (upd) S[5 * kMat + sub] = make_double2(dg + 0.5 * a.x, 0.5 * a.y);
       __syncthreads();
       double2 y = make_double2(0.0, 0.0);  // (I + a/2) U
 #pragma unroll
@@ -359,8 +470,8 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
       // the matrix is the identity and elimination without pivoting is stable.
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        S[6 * kMat + sub] = mm;
-        S[7 * kMat + sub] = y;
+        if (upd) S[6 * kMat + sub] = mm;
+        if (upd) S[7 * kMat + sub] = y;
         __syncthreads();
         const double2 inv = cinv(S[6 * kMat + p * 4 + p]);
         const double2 mpj = S[6 * kMat + p * 4 + j], ypj = S[7 * kMat + p * 4 + j];
@@ -374,7 +485,7 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
         }
         __syncthreads();
       }
-      S[8 * kMat + sub] = y;  // the new gate
+      if (upd) S[8 * kMat + sub] = y;  // the new gate
       double df = (y.x - u.x) * (y.x - u.x) + (y.y - u.y) * (y.y - u.y);
 #pragma unroll
       for (int m = 1; m < 16; m <<= 1) df += shfl_xor_d(df, m);
@@ -387,8 +498,8 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
           tm = cadd(tm, cmulc(S[8 * kMat + i * 4 + l], S[3 * kMat + j * 4 + l]));
           tv = cadd(tv, cmulc(S[8 * kMat + i * 4 + l], S[4 * kMat + j * 4 + l]));
         }
-        S[0 * kMat + sub] = tm;
-        S[1 * kMat + sub] = tv;
+        if (upd) S[0 * kMat + sub] = tm;
+        if (upd) S[1 * kMat + sub] = tv;
       }
       __syncthreads();
       if (!A.frozen) {
@@ -407,6 +518,7 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
       __syncthreads();
     }
 
+    STAMP(4);
     // ---- bookkeeping of minimize() (:124-147), identical in every thread
     if (tid == 0) A.hist[inst * (long)A.max_iter + it] = val;
     ++it;
@@ -420,6 +532,10 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
     if (dsum / G < A.param_tol) break;
   }
   for (int e = tid; e < G * kMat; e += NT) A.final_g[gbase + e] = U[e];
+#ifdef MPS2QC_STAMPS
+  if (tid == 0)  // diagnostic build only: cycles of forward / overlap / env / backward applies / update
+    for (int q = 0; q < 5; ++q) A.envs[gbase + q] = make_double2((double)st_c[q], 0.0);
+#endif
   if (tid == 0) {
     A.best_val[inst] = best_val;
     A.n_iter[inst] = it;
@@ -501,18 +617,20 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
     lr_t[it] = lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t));
   }
 
-  const int NT = n <= 8 ? 64 : 256;
+  // threads per fit: enough waves per SIMD to hide the LDS latency of the gate sweeps
+  int NT = n <= 8 ? 64 : n <= 10 ? 256 : 512;
+  if (n == 12 && getenv("MPS2QC_NT12")) NT = atoi(getenv("MPS2QC_NT12")) == 1024 ? 1024 : 512;  // experiments
   const size_t dim = (size_t)1 << n;
   FitArgs A;
   memset(&A, 0, sizeof A);
   size_t off = 2 * dim * 16;
   A.off_u = (int)off, off += (size_t)G * kMat * 16;
   A.off_e = (int)off, off += (size_t)G * kMat * 16;
-  A.off_red = (int)off, off += (size_t)(NT / 64) * 256 * 8;
-  A.off_sc = (int)off, off += 16 * 8;
+  A.off_red = (int)off, off += (size_t)(NT / 64) * 64 * 8;
+  A.off_sc = (int)off, off += 2 * 16 * 8;  // one complex partial per wave (<= 16 waves)
   A.off_dn = (int)off, off += (size_t)((G + 1) & ~1) * 8;
   A.off_lo = (int)off, off += (size_t)((G + 3) & ~3) * 4;
-  const size_t scratch = (size_t)(NT / 16) * kSlotMats * kMat * 16;
+  const size_t scratch = (size_t)(NT / 16 < 16 ? NT / 16 : 16) * kSlotMats * kMat * 16;
   if (2 * dim * 16 >= scratch) A.off_scratch = 0;  // overlay on psi / phi, idle during the update
   else A.off_scratch = (int)off, off += scratch;
   if (off > (size_t)kLdsLimit) {
@@ -568,7 +686,8 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
     switch (n) {
 #define CASE(NN, TT) case NN: le = launch<NN, TT>(A, batch, off, st); break;
       CASE(2, 64) CASE(3, 64) CASE(4, 64) CASE(5, 64) CASE(6, 64) CASE(7, 64) CASE(8, 64)
-      CASE(9, 256) CASE(10, 256) CASE(11, 256) CASE(12, 256)
+      CASE(9, 256) CASE(10, 256) CASE(11, 512)
+      case 12: le = NT == 512 ? launch<12, 512>(A, batch, off, st) : launch<12, 1024>(A, batch, off, st); break;
 #undef CASE
     }
     HIP_TRY(le);
