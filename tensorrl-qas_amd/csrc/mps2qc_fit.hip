@@ -86,7 +86,9 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xo
 // makes every aligned group of 16 lanes cover all 16 bank groups for every lo.
 __device__ __forceinline__ int sw(int idx) { return idx ^ (((idx >> 4) & 3) * 5); }
 
-// 4x4 gate (or its adjoint) from LDS into registers: wave-uniform broadcast reads.
+// 4x4 gate (or its adjoint) from LDS into registers: wave-uniform broadcast reads.  (Moving the
+// matrix to SGPRs with v_readfirstlane was measured: 64 extra instructions per sweep and SGPR
+// spills, 13 % slower at 12 qubits.)
 __device__ __forceinline__ void load_gate(double2 (&m)[16], const double2* M, bool dagger) {
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -299,7 +301,7 @@ __device__ __forceinline__ double2 env_valu_combine(const double* red, int t) {
   return make_double2(x, y);
 }
 
-template <int N, int NT>
+template <int N, int NT, bool MFMA>
 __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int DIM = 1 << N;
@@ -384,12 +386,12 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
     STAMP(1);
     // ---- backward: environments
     for (int k = G - 1; k >= 0; --k) {
-      if (A.use_mfma) env_mfma<N, NT>(phi, psi, lo_s[k], red, tid);
+      if constexpr (MFMA) env_mfma<N, NT>(phi, psi, lo_s[k], red, tid);
       else env_valu<N, NT>(phi, psi, lo_s[k], red, tid);
       __syncthreads();
       STAMP(2);
       if (tid < 16)
-        E[k * kMat + tid] = A.use_mfma ? env_mfma_combine<NT>(red, tid) : env_valu_combine<NT>(red, tid);
+        E[k * kMat + tid] = MFMA ? env_mfma_combine<NT>(red, tid) : env_valu_combine<NT>(red, tid);
       if (k > 0) {  // nothing reads phi_0 / psi_{-1}
         if constexpr ((1 << (N - 2)) <= NT) {
           apply_two<N, NT>(phi, U + k * kMat, lo_s[k], psi, U + (k - 1) * kMat, lo_s[k - 1], tid);
@@ -552,13 +554,19 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
     }                                                                                     \
   } while (0)
 
-template <int N, int NT>
-hipError_t launch(const FitArgs& A, int batch, size_t lds, hipStream_t st) {
-  auto fn = reinterpret_cast<const void*>(&k_fit<N, NT>);
+template <int N, int NT, bool MFMA>
+hipError_t launch2(const FitArgs& A, int batch, size_t lds, hipStream_t st) {
+  auto fn = reinterpret_cast<const void*>(&k_fit<N, NT, MFMA>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_fit<N, NT>), dim3((unsigned)batch), dim3(NT), lds, st, A);
+  hipLaunchKernelGGL((k_fit<N, NT, MFMA>), dim3((unsigned)batch), dim3(NT), lds, st, A);
   return hipGetLastError();
+}
+// the vector-FMA environments are a kernel of their own: their 32 accumulators per thread would
+// otherwise set the register allocation of the MFMA kernel too
+template <int N, int NT>
+hipError_t launch(const FitArgs& A, int batch, size_t lds, hipStream_t st) {
+  return A.use_mfma ? launch2<N, NT, true>(A, batch, lds, st) : launch2<N, NT, false>(A, batch, lds, st);
 }
 
 }  // namespace
