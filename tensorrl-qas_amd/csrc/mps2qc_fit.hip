@@ -49,7 +49,9 @@ struct FitArgs {
   double2* envs;          // [B][G][16]
   double2* overlap;       // [B]
   // LDS layout (bytes from the start of dynamic LDS), decided by the host
-  int off_u, off_e, off_red, off_sc, off_dn, off_lo, off_scratch;
+  int off_u, off_e, off_red, off_sc, off_dn, off_lo, off_scratch, off_grp;
+  const int* grp;         // [n_groups][2] first gate and size of every run of mutually disjoint gates
+  int n_groups;
 };
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
@@ -82,9 +84,16 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xo
 
 // Physical LDS slot of amplitude idx.  A thread reads the four amplitudes idx | b << lo of its
 // 4-vector with ds_read_b128; for lo < 4 sixteen neighbouring lanes would otherwise meet in 4 (lo
-// <= 2) or 8 of the 16 16-byte bank groups.  XORing bits 0/2 with bit 4 and bits 1/3 with bit 5
-// makes every aligned group of 16 lanes cover all 16 bank groups for every lo.
-__device__ __forceinline__ int sw(int idx) { return idx ^ (((idx >> 4) & 3) * 5); }
+// <= 2) or 8 of the 16 16-byte slots of a bank row.  XORing bits 0/2 with bit 4 and bits 1/3 with
+// bit 5 spreads them over all 16 (measured: -6 % per step at 12 qubits).  The map is GF(2)-linear,
+// so sw(base | field) = sw(base) ^ sw(field): one XOR per address, the wave-uniform part in scalar
+// registers.  (A wider map that also folds bits 6..11 in, meant to separate the four rows of an MFMA
+// operand read and the lanes of a pair sweep, was measured 15 % SLOWER and dropped.)
+__device__ __forceinline__ int sw(int idx) {
+  return idx ^ (((idx >> 4) & 3) * 5);
+}
+__device__ __forceinline__ int ins2(int r, int lo) { return ((r >> lo) << (lo + 2)) | (r & ((1 << lo) - 1)); }
+__device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // 4x4 gate (or its adjoint) from LDS into registers: wave-uniform broadcast reads.  (Moving the
 // matrix to SGPRs with v_readfirstlane was measured: 64 extra instructions per sweep and SGPR
@@ -121,19 +130,22 @@ __device__ __forceinline__ void mat4(const double2 (&m)[16], double2 (&v)[IT][4]
 // st <- m on the qubit pair whose low bit is `lo`; every thread owns whole 4-vectors.  The trip
 // count is a compile-time constant and all LDS reads are issued before the arithmetic.
 template <int N, int NT>
-__device__ __forceinline__ void apply_gate(double2* st, const double2 (&m)[16], int lo, int tid) {
+__device__ __forceinline__ void apply_gate(double2* st, const double2 (&m)[16], int lo_, int tid) {
   constexpr int R = 1 << (N - 2);
   constexpr int IT = R >= NT ? R / NT : 1;
-  const int lmask = (1 << lo) - 1;
+  const int lo = sgpr(lo_);
+  int fb[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) fb[b] = sw(b << lo);
   double2 v[IT][4];
   int base[IT];
 #pragma unroll
   for (int t = 0; t < IT; ++t) {
     const int r = tid + t * NT;
-    base[t] = ((r >> lo) << (lo + 2)) | (r & lmask);
+    base[t] = sw(ins2(r, lo));
     if (R >= NT || r < R) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) v[t][b] = st[sw(base[t] | (b << lo))];
+      for (int b = 0; b < 4; ++b) v[t][b] = st[base[t] ^ fb[b]];
     }
   }
   mat4<IT>(m, v);
@@ -141,30 +153,33 @@ __device__ __forceinline__ void apply_gate(double2* st, const double2 (&m)[16], 
   for (int t = 0; t < IT; ++t)
     if (R >= NT || tid + t * NT < R) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) st[sw(base[t] | (a << lo))] = v[t][a];
+      for (int a = 0; a < 4; ++a) st[base[t] ^ fb[a]] = v[t][a];
     }
 }
 
 // Two independent sweeps (phi <- m1 phi, psi <- m2 psi) in one barrier interval, their LDS reads
 // in flight together.
 template <int N, int NT>
-__device__ __forceinline__ void apply_two(double2* s1, const double2* M1, int lo1, double2* s2, const double2* M2,
-                                          int lo2, int tid) {
+__device__ __forceinline__ void apply_two(double2* s1, const double2* M1, int lo1_, double2* s2, const double2* M2,
+                                          int lo2_, int tid) {
   constexpr int R = 1 << (N - 2);
   constexpr int IT = R >= NT ? R / NT : 1;
-  const int lm1 = (1 << lo1) - 1, lm2 = (1 << lo2) - 1;
+  const int lo1 = sgpr(lo1_), lo2 = sgpr(lo2_);
+  int f1[4], f2[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) f1[b] = sw(b << lo1), f2[b] = sw(b << lo2);
   double2 v1[IT][4], v2[IT][4];
   int b1[IT], b2[IT];
 #pragma unroll
   for (int t = 0; t < IT; ++t) {
     const int r = tid + t * NT;
-    b1[t] = ((r >> lo1) << (lo1 + 2)) | (r & lm1);
-    b2[t] = ((r >> lo2) << (lo2 + 2)) | (r & lm2);
+    b1[t] = sw(ins2(r, lo1));
+    b2[t] = sw(ins2(r, lo2));
     if (R >= NT || r < R) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) v1[t][b] = s1[sw(b1[t] | (b << lo1))];
+      for (int b = 0; b < 4; ++b) v1[t][b] = s1[b1[t] ^ f1[b]];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) v2[t][b] = s2[sw(b2[t] | (b << lo2))];
+      for (int b = 0; b < 4; ++b) v2[t][b] = s2[b2[t] ^ f2[b]];
     }
   }
   {
@@ -176,7 +191,7 @@ __device__ __forceinline__ void apply_two(double2* s1, const double2* M1, int lo
   for (int t = 0; t < IT; ++t)
     if (R >= NT || tid + t * NT < R) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) s1[sw(b1[t] | (a << lo1))] = v1[t][a];
+      for (int a = 0; a < 4; ++a) s1[b1[t] ^ f1[a]] = v1[t][a];
     }
   {
     double2 m[16];
@@ -187,8 +202,112 @@ __device__ __forceinline__ void apply_two(double2* s1, const double2* M1, int lo
   for (int t = 0; t < IT; ++t)
     if (R >= NT || tid + t * NT < R) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) s2[sw(b2[t] | (a << lo2))] = v2[t][a];
+      for (int a = 0; a < 4; ++a) s2[b2[t] ^ f2[a]] = v2[t][a];
     }
+}
+
+// ---- sweeps of the half-layer scheme ---------------------------------------------------------
+// The gates of a run of mutually disjoint gates (a brickwork half layer) commute.  With
+// psi_b = the state before the run and phi_H = the target with the WHOLE run removed,
+//   E_k = conj(U_k) F_k,   F_k[a,b] = sum_r conj(phi_H[a,r]) psi_b[b,r]
+// for every gate k of the run: no intermediate state is needed, so two gates are applied per
+// sweep (a thread owns the 16 amplitudes of both qubit pairs: half the LDS traffic and half
+// the barriers) and the environments of a run are MFMA passes over the same two vectors.
+// v[.][b] <- m v[.][b] for the four column vectors of a 4x4 block of amplitudes
+__device__ __forceinline__ void mat4_cols(const double2 (&m)[16], double2 (&v)[4][4]) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    double2 w[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double2 s = cmul(m[a * 4], v[0][b]);
+#pragma unroll
+      for (int c = 1; c < 4; ++c) s = cmac(s, m[a * 4 + c], v[c][b]);
+      w[a] = s;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) v[a][b] = w[a];
+  }
+}
+
+// NS state vectors (contiguous in LDS) <- gate A (x) gate B, loA > loB + 1
+template <int N, int NT, int NS>
+__device__ __forceinline__ void sweep_pair(double2* st, const double2* MA, int loA_, const double2* MB, int loB_,
+                                           bool dagger, int tid) {
+  const int loA = sgpr(loA_), loB = sgpr(loB_);
+  constexpr int V = 1 << (N - 4);
+  constexpr int ITEMS = NS * V;
+  constexpr int IT = (ITEMS + NT - 1) / NT;
+#pragma unroll 1
+  for (int t = 0; t < IT; ++t) {
+    const int item = tid + t * NT;
+    if (ITEMS % NT == 0 || item < ITEMS) {
+      double2* s = st + (item >> (N - 4)) * (1 << N);
+      const int base = sw(ins2(ins2(item & (V - 1), loB), loA));
+      double2 v[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[a][b] = s[base ^ sw((a << loA) | (b << loB))];
+      {
+        double2 m[16];
+        load_gate(m, MB, dagger);
+        mat4<4>(m, v);
+      }
+      __asm__ volatile("" ::: "memory");  // keep the second matrix out of registers until the first is done
+      {
+        double2 m[16];
+        load_gate(m, MA, dagger);
+        mat4_cols(m, v);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s[base ^ sw((a << loA) | (b << loB))] = v[a][b];
+    }
+  }
+}
+
+// NS state vectors <- one gate (the odd gate of a run)
+template <int N, int NT, int NS>
+__device__ __forceinline__ void sweep_single(double2* st, const double2* M, int lo_, bool dagger, int tid) {
+  const int lo = sgpr(lo_);
+  constexpr int R = 1 << (N - 2);
+  constexpr int ITEMS = NS * R;
+  constexpr int IT = (ITEMS + NT - 1) / NT;
+  double2 m[16];
+  load_gate(m, M, dagger);
+#pragma unroll 1
+  for (int t = 0; t < IT; ++t) {
+    const int item = tid + t * NT;
+    if (ITEMS % NT == 0 || item < ITEMS) {
+      double2* s = st + (item >> (N - 2)) * (1 << N);
+      const int base = sw(ins2(item & (R - 1), lo));
+      double2 v[1][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v[0][b] = s[base ^ sw(b << lo)];
+      mat4<1>(m, v);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) s[base ^ sw(b << lo)] = v[0][b];
+    }
+  }
+}
+
+// all gates of run [first, first + cnt) on NS state vectors, a barrier after every sweep
+template <int N, int NT, int NS>
+__device__ __forceinline__ void sweep_run(double2* st, const double2* U, const int* lo_s, int first, int cnt,
+                                          bool dagger, int tid) {
+  for (int i = 0; i < cnt; i += 2) {
+    const int g0 = first + i;
+    if (i + 1 < cnt) {
+      const int l0 = lo_s[g0], l1 = lo_s[g0 + 1];
+      if (l0 > l1) sweep_pair<N, NT, NS>(st, U + g0 * kMat, l0, U + (g0 + 1) * kMat, l1, dagger, tid);
+      else sweep_pair<N, NT, NS>(st, U + (g0 + 1) * kMat, l1, U + g0 * kMat, l0, dagger, tid);
+    } else {
+      sweep_single<N, NT, NS>(st, U + g0 * kMat, lo_s[g0], dagger, tid);
+    }
+    __syncthreads();
+  }
 }
 
 // Environment partials on the matrix cores.  One v_mfma_f64_16x16x4_f64 consumes 8 values of
@@ -196,27 +315,30 @@ __device__ __forceinline__ void apply_two(double2* s1, const double2* M1, int lo
 // B = psi, k = 4 values of r per slice; only the s == s' blocks are meaningful and kept.
 // A[i][k]: lane = i + 16 k; C[row][col]: col = lane & 15, row = (lane >> 4) + 4 reg.
 template <int N, int NT>
-__device__ __forceinline__ void env_mfma(const double2* phi, const double2* psi, int lo, double* red,
+__device__ __forceinline__ void env_mfma(const double2* phi, const double2* psi, int lo_, double* red,
                                          int tid) {
+  const int lo = sgpr(lo_);
   constexpr int R = 1 << (N - 2);
   constexpr int NW = NT / 64;
   constexpr int CH = (R + 7) / 8;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, k = lane >> 4;
   const int s = i >> 3, c = (i >> 2) & 1, a = i & 3;
-  const int lmask = (1 << lo) - 1;
   // compile-time trip count: all operand reads of the wave are issued before the first MFMA
   // and two accumulators break the dependency chain
   constexpr int TR = (CH + NW - 1) / NW;
   double av[TR], bv[TR];
+  // address = (lane part: row a, slice s, k-step, re/im) ^ (chunk part, wave-uniform): bit
+  // permutations and the swizzle are GF(2)-linear
+  const int lane_off = sw(ins2(s * 4 + k, lo) | (a << lo)) * 2 + c;
 #pragma unroll
   for (int t = 0; t < TR; ++t) {
-    const int r = (wave + t * NW) * 8 + s * 4 + k;
+    const int ch = sgpr(wave + t * NW);
     av[t] = 0.0, bv[t] = 0.0;
-    if ((R >= 8 && CH % NW == 0) || r < R) {
-      const int idx = sw(((r >> lo) << (lo + 2)) | (a << lo) | (r & lmask));
-      av[t] = reinterpret_cast<const double*>(phi)[2 * idx + c];
-      bv[t] = reinterpret_cast<const double*>(psi)[2 * idx + c];
+    if ((R >= 8 && CH % NW == 0) || ch * 8 + s * 4 + k < R) {
+      const int off = lane_off ^ (sw(ins2(ch * 8, lo)) * 2);
+      av[t] = reinterpret_cast<const double*>(phi)[off];
+      bv[t] = reinterpret_cast<const double*>(psi)[off];
     }
   }
   d4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
@@ -301,7 +423,7 @@ __device__ __forceinline__ double2 env_valu_combine(const double* red, int t) {
   return make_double2(x, y);
 }
 
-template <int N, int NT, bool MFMA>
+template <int N, int NT, bool MFMA, bool GRP>
 __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int DIM = 1 << N;
@@ -315,6 +437,7 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
   double* sc = reinterpret_cast<double*>(smem + A.off_sc);
   double* dnorm = reinterpret_cast<double*>(smem + A.off_dn);
   int* lo_s = reinterpret_cast<int*>(smem + A.off_lo);
+  int* grp_s = reinterpret_cast<int*>(smem + A.off_grp);
   double2* scratch = reinterpret_cast<double2*>(smem + A.off_scratch);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -331,6 +454,8 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
     }
   }
   for (int k = tid; k < G; k += NT) lo_s[k] = A.lo[k];
+  if (GRP)
+    for (int k = tid; k < 2 * A.n_groups; k += NT) grp_s[k] = A.grp[k];
   __syncthreads();
 
   double best_val = 10000.0;  // stiefel_opt.py:122
@@ -345,11 +470,16 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
     // ---- forward
     for (int i = tid; i < DIM; i += NT) psi[i] = make_double2(i == 0 ? 1.0 : 0.0, 0.0);  // sw(0) = 0
     __syncthreads();
-    for (int k = 0; k < G; ++k) {
-      double2 m[16];
-      load_gate(m, U + k * kMat, false);
-      apply_gate<N, NT>(psi, m, lo_s[k], tid);
-      __syncthreads();
+    if constexpr (GRP) {
+      for (int gi = 0; gi < A.n_groups; ++gi)
+        sweep_run<N, NT, 1>(psi, U, lo_s, grp_s[2 * gi], grp_s[2 * gi + 1], false, tid);
+    } else {
+      for (int k = 0; k < G; ++k) {
+        double2 m[16];
+        load_gate(m, U + k * kMat, false);
+        apply_gate<N, NT>(psi, m, lo_s[k], tid);
+        __syncthreads();
+      }
     }
     STAMP(0);
     // ---- overlap o = <t|psi>, phi <- t
@@ -371,12 +501,12 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
       }
     }
     __syncthreads();
-    {
+    if constexpr (!GRP) {
       double2 m[16];
       load_gate(m, U + (G - 1) * kMat, true);
       apply_gate<N, NT>(psi, m, lo_s[G - 1], tid);
+      __syncthreads();
     }
-    __syncthreads();
     double2 o = make_double2(0.0, 0.0);
     for (int w = 0; w < NW; ++w) o = cadd(o, make_double2(sc[2 * w], sc[2 * w + 1]));
     const double abso = hypot(o.x, o.y);
@@ -385,6 +515,24 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
 
     STAMP(1);
     // ---- backward: environments
+    if constexpr (GRP) {
+      // per run, last to first: remove the whole run from psi and phi (pair sweeps on both
+      // vectors at once), then one MFMA pass per gate over the same two vectors; E holds F_k
+      int nenv = 0;
+      for (int gi = A.n_groups - 1; gi >= 0; --gi) {
+        const int first = grp_s[2 * gi], cnt = grp_s[2 * gi + 1];
+        sweep_run<N, NT, 2>(psi, U, lo_s, first, cnt, true, tid);
+        STAMP(3);
+        for (int k = first + cnt - 1; k >= first; --k, ++nenv) {
+          double* rb = red + (nenv & 1) * (NW * 64);  // double buffered: one barrier per gate
+          env_mfma<N, NT>(phi, psi, lo_s[k], rb, tid);
+          __syncthreads();
+          if (tid < 16) E[k * kMat + tid] = env_mfma_combine<NT>(rb, tid);
+        }
+        STAMP(2);
+      }
+      __syncthreads();
+    } else {
     for (int k = G - 1; k >= 0; --k) {
       if constexpr (MFMA) env_mfma<N, NT>(phi, psi, lo_s[k], red, tid);
       else env_valu<N, NT>(phi, psi, lo_s[k], red, tid);
@@ -406,8 +554,17 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
       __syncthreads();
       STAMP(3);
     }
+    }
     if (A.envs)
-      for (int e = tid; e < G * kMat; e += NT) A.envs[gbase + e] = E[e];
+      for (int e = tid; e < G * kMat; e += NT) {
+        double2 ev = E[e];
+        if constexpr (GRP) {  // E_k = conj(U_k) F_k
+          const int k = e >> 4, i = (e >> 2) & 3, j = e & 3;
+          ev = make_double2(0.0, 0.0);
+          for (int l = 0; l < 4; ++l) ev = cadd(ev, cmulc(E[k * kMat + l * 4 + j], U[k * kMat + i * 4 + l]));
+        }
+        A.envs[gbase + e] = ev;
+      }
     if (A.overlap && tid == 0) A.overlap[inst] = o;
 
     // ---- StiefelAdam.update, 16 lanes per gate; scratch overlays the idle state vectors
@@ -423,7 +580,12 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
       const int kk = act ? k : 0;
       const double2* Uk = U + kk * kMat;
       const double2 u = Uk[sub];
-      const double2 Ee = E[kk * kMat + sub];
+      double2 Ee = E[kk * kMat + sub];
+      if constexpr (GRP) {  // E_k = conj(U_k) F_k
+        Ee = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) Ee = cadd(Ee, cmulc(E[kk * kMat + l * 4 + j], Uk[i * 4 + l]));
+      }
       // Euclidean gradient handed to update(): -(o/|o|) conj(E)
       const double2 g = cmul(make_double2(-ph.x, -ph.y), make_double2(Ee.x, -Ee.y));
       if (upd) S[0 * kMat + sub] = g;
@@ -554,19 +716,22 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
     }                                                                                     \
   } while (0)
 
-template <int N, int NT, bool MFMA>
+template <int N, int NT, bool MFMA, bool GRP>
 hipError_t launch2(const FitArgs& A, int batch, size_t lds, hipStream_t st) {
-  auto fn = reinterpret_cast<const void*>(&k_fit<N, NT, MFMA>);
+  auto fn = reinterpret_cast<const void*>(&k_fit<N, NT, MFMA, GRP>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_fit<N, NT, MFMA>), dim3((unsigned)batch), dim3(NT), lds, st, A);
+  hipLaunchKernelGGL((k_fit<N, NT, MFMA, GRP>), dim3((unsigned)batch), dim3(NT), lds, st, A);
   return hipGetLastError();
 }
 // the vector-FMA environments are a kernel of their own: their 32 accumulators per thread would
 // otherwise set the register allocation of the MFMA kernel too
 template <int N, int NT>
-hipError_t launch(const FitArgs& A, int batch, size_t lds, hipStream_t st) {
-  return A.use_mfma ? launch2<N, NT, true>(A, batch, lds, st) : launch2<N, NT, false>(A, batch, lds, st);
+hipError_t launch(const FitArgs& A, int batch, size_t lds, hipStream_t st, bool grouped) {
+  if constexpr (N >= 10) {
+    if (grouped) return launch2<N, NT, true, true>(A, batch, lds, st);
+  }
+  return A.use_mfma ? launch2<N, NT, true, false>(A, batch, lds, st) : launch2<N, NT, false, false>(A, batch, lds, st);
 }
 
 }  // namespace
@@ -626,18 +791,36 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
   }
 
   // threads per fit: enough waves per SIMD to hide the LDS latency of the gate sweeps
-  int NT = n <= 8 ? 64 : n <= 10 ? 256 : 512;
-  if (n == 12 && getenv("MPS2QC_NT12")) NT = atoi(getenv("MPS2QC_NT12")) == 1024 ? 1024 : 512;  // experiments
+  // threads per fit: enough waves per SIMD to hide the LDS latency of the gate sweeps
+  const int NT = n <= 8 ? 64 : n <= 10 ? 256 : 512;
+  // runs of mutually disjoint gates (brickwork half layers) for the half-layer scheme
+  std::vector<int> grp;
+  {
+    unsigned used = 0;
+    for (int k = 0; k < G; ++k) {
+      const unsigned bits = 3u << lo[k];
+      if (grp.empty() || (used & bits)) {
+        grp.push_back(k), grp.push_back(0);
+        used = 0;
+      }
+      used |= bits;
+      ++grp.back();
+    }
+  }
+  // the half-layer scheme pays at 12 qubits (-9 % per step); at 10 / 11 qubits it leaves too many
+  // threads idle in the pair sweeps and is 5-20 % slower
+  bool grouped = use_mfma && n >= (getenv("MPS2QC_GROUPED") ? 10 : 12) && !(getenv("MPS2QC_GROUPED") && atoi(getenv("MPS2QC_GROUPED")) == 0);
   const size_t dim = (size_t)1 << n;
   FitArgs A;
   memset(&A, 0, sizeof A);
   size_t off = 2 * dim * 16;
   A.off_u = (int)off, off += (size_t)G * kMat * 16;
   A.off_e = (int)off, off += (size_t)G * kMat * 16;
-  A.off_red = (int)off, off += (size_t)(NT / 64) * 64 * 8;
+  A.off_red = (int)off, off += (size_t)2 * (NT / 64) * 64 * 8;  // double buffered (half-layer scheme)
   A.off_sc = (int)off, off += 2 * 16 * 8;  // one complex partial per wave (<= 16 waves)
   A.off_dn = (int)off, off += (size_t)((G + 1) & ~1) * 8;
   A.off_lo = (int)off, off += (size_t)((G + 3) & ~3) * 4;
+  A.off_grp = (int)off, off += (size_t)((grp.size() + 3) & ~(size_t)3) * 4;
   const size_t scratch = (size_t)(NT / 16 < 16 ? NT / 16 : 16) * kSlotMats * kMat * 16;
   if (2 * dim * 16 >= scratch) A.off_scratch = 0;  // overlay on psi / phi, idle during the update
   else A.off_scratch = (int)off, off += scratch;
@@ -649,7 +832,7 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
 
   const size_t gsz = (size_t)batch * G * kMat * 16;
   const size_t tsz = (target_shared ? 1 : (size_t)batch) * dim * 16;
-  int* d_lo = nullptr;
+  int *d_lo = nullptr, *d_grp = nullptr;
   double *d_lr = nullptr, *d_hist = nullptr, *d_bv = nullptr;
   double2 *d_t = nullptr, *d_init = nullptr, *d_fin = nullptr, *d_best = nullptr, *d_m = nullptr, *d_v = nullptr,
           *d_env = nullptr, *d_ov = nullptr;
@@ -663,6 +846,7 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipMalloc(&d_lo, G * sizeof(int)));
+  HIP_TRY(hipMalloc(&d_grp, grp.size() * sizeof(int)));
   HIP_TRY(hipMalloc(&d_lr, max_iter * sizeof(double)));
   HIP_TRY(hipMalloc(&d_hist, (size_t)batch * max_iter * sizeof(double)));
   HIP_TRY(hipMalloc(&d_bv, batch * sizeof(double)));
@@ -676,6 +860,7 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
   HIP_TRY(hipMalloc(&d_env, gsz));
   HIP_TRY(hipMalloc(&d_ov, batch * 16));
   HIP_TRY(hipMemcpyAsync(d_lo, lo.data(), G * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_grp, grp.data(), grp.size() * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_lr, lr_t.data(), max_iter * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_t, target, tsz, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_init, init_gates, gsz, hipMemcpyHostToDevice, st));
@@ -685,6 +870,7 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
   A.G = G, A.max_iter = max_iter, A.frozen = jit_frozen ? 1 : 0, A.use_mfma = use_mfma ? 1 : 0;
   A.target_shared = target_shared ? 1 : 0;
   A.beta1 = beta1, A.beta2 = beta2, A.eps = eps, A.tol = tol, A.param_tol = param_tol;
+  A.grp = d_grp, A.n_groups = (int)grp.size() / 2;
   A.lo = d_lo, A.lr_t = d_lr, A.target = d_t, A.init = d_init, A.final_g = d_fin, A.best_g = d_best;
   A.mom = d_m, A.vel = d_v, A.hist = d_hist, A.best_val = d_bv, A.n_iter = d_ni, A.envs = d_env, A.overlap = d_ov;
 
@@ -692,10 +878,10 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
   {
     hipError_t le = hipErrorInvalidValue;
     switch (n) {
-#define CASE(NN, TT) case NN: le = launch<NN, TT>(A, batch, off, st); break;
+#define CASE(NN, TT) case NN: le = launch<NN, TT>(A, batch, off, st, grouped); break;
       CASE(2, 64) CASE(3, 64) CASE(4, 64) CASE(5, 64) CASE(6, 64) CASE(7, 64) CASE(8, 64)
       CASE(9, 256) CASE(10, 256) CASE(11, 512)
-      case 12: le = NT == 512 ? launch<12, 512>(A, batch, off, st) : launch<12, 1024>(A, batch, off, st); break;
+      CASE(12, 512)
 #undef CASE
     }
     HIP_TRY(le);
@@ -714,7 +900,7 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
   if (last_overlap) HIP_TRY(hipMemcpy(last_overlap, d_ov, (size_t)batch * 16, hipMemcpyDeviceToHost));
 
 done:
-  for (void* p : {(void*)d_lo, (void*)d_lr, (void*)d_hist, (void*)d_bv, (void*)d_ni, (void*)d_t, (void*)d_init,
+  for (void* p : {(void*)d_grp, (void*)d_lo, (void*)d_lr, (void*)d_hist, (void*)d_bv, (void*)d_ni, (void*)d_t, (void*)d_init,
                   (void*)d_fin, (void*)d_best, (void*)d_m, (void*)d_v, (void*)d_env, (void*)d_ov})
     (void)hipFree(p);
   if (e0) (void)hipEventDestroy(e0);
