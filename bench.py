@@ -199,6 +199,12 @@ def mps2qc_aux(tq, dev, with_cpu):
                         "algorithmic_flop_per_step": 4 * G * (1 << n) * 32,
                         "note": "environments on v_mfma_f64_16x16x4_f64, gate sweeps on FP64 vector FMAs; "
                                 "both pipes peak at the same 78.6 TFLOP/s on MI355X; states LDS-resident"}}
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic_mps2qc.json")
+    if os.path.exists(tfile):      # HBM bytes per launch from a separate rocprofv3 --pmc run
+        tr = json.load(open(tfile))
+        if tr.get("workload") == out["workload"]:
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr["source"]
     if with_cpu:      # the numpy restatement (oracle/stiefel_oracle.py) on one fit, a few steps
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import stiefel_oracle as so
