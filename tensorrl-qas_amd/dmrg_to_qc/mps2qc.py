@@ -52,3 +52,13 @@ def mps_to_qc(mps, ansatz=None, optimizer_opts=None, n_restarts=1, rng=None, ini
     gates = opt.opt_params if best is None else opt.opt_params[best]
     hist = opt.loss_history if best is None else opt.loss_history[best]
     return [g for g in gates], hist, {k: g for k, g in enumerate(gates)}
+
+
+def write_init_circuit(path, num_qubits, sites, gates, rng=None):
+    """Write ``init_<mol>_TNbond<chi>.qasm`` (what dmrg_to_qc.py:298 dumps with qiskit): the file
+    the environments read their init circuit from."""
+    from .su4_to_qasm import brickwork_to_qasm
+    text = brickwork_to_qasm(num_qubits, sites, gates, rng)
+    with open(path, "w") as f:
+        f.write(text)
+    return text

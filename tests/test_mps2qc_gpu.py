@@ -143,3 +143,32 @@ def test_mfma_and_valu_agree_and_errors():
     with pytest.raises(VQEError):
         dq.StiefelAdam().minimize(dq.BrickworkOverlap(12, s12, np.ones(1 << 12, complex) / 64),
                                   np.tile(np.eye(4), (1, G12, 1, 1)), max_iter=1)
+
+
+def test_fit_to_qasm_to_engine_state(tmp_path):
+    """The offline pipeline end to end: fit on the GPU -> {rz, ry, cx} text -> the reader and the
+    state-vector engine the environments use.  The engine's state equals the brickwork state of
+    the fitted gates (register qubit k = MPS site k), and its overlap with the target is the one
+    the fit reports."""
+    import tensorrl_qas_amd as tq
+    from tensorrl_qas_amd import dmrg_to_qc as dq
+    psi_t = oracle_init_state(load_case("BEH2_6q"))          # little-endian target from the shipped circuit
+    n = 6
+    rev = np.array([int(format(i, f"0{n}b")[::-1], 2) for i in range(1 << n)])
+    target = psi_t[rev]                                       # site 0 most significant
+    rng = np.random.default_rng(3)
+    opt = dq.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=True)
+    gates, hist, _ = dq.mps_to_qc(target, {"structure": "brickwork", "num_layers": 1},
+                                  {"method": opt, "max_iter": 1500, "tol": 1e-8}, n_restarts=32, rng=rng)
+    sites, G = dq.brickwork_ansatz(n, 1)
+    path = tmp_path / "init_BEH2_6q_TNbond2.qasm"
+    dq.mps2qc.write_init_circuit(path, n, sites, gates, rng)
+    nq, parsed = tq.qasm.parse(open(path).read())
+    circ, ang = tq.circuits.circuit_from_qasm_gates(parsed)
+    eng = tq.VQEEngine(n, 0)
+    eng.set_circuit(circ)
+    state = eng.get_state(ang)
+    ref = so.circuit_state(n, list(sites), gates)
+    assert abs(abs(np.vdot(ref[rev], state)) - 1) < 1e-9
+    assert abs((1 - abs(np.vdot(psi_t, state))) - so.loss(n, list(sites), gates, target)) < 1e-9
+    assert 1 - abs(np.vdot(psi_t, state)) < np.min(opt.best_val) + 1e-2

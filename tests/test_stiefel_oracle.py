@@ -96,3 +96,40 @@ def test_mps_to_dense_and_cayley_identities():
     w = so.cayley_retraction(0.1 * so.riemannian_grad(x, u), u)
     assert np.max(np.abs(w @ w.conj().T - np.eye(4))) < 1e-13
     assert np.max(np.abs(closest_unitary(u + 1e-9 * x) - u)) < 1e-8
+
+
+def test_brickwork_to_qasm_reproduces_the_state():
+    """Fitted gates -> {rz, ry, cx} text (3 CX per SU(4) block) -> the reader and simulator the
+    environments use: same state as the brickwork circuit, register qubit k = MPS site k
+    (little-endian statevector = bit reversal of the site-0-major dense vector)."""
+    import vqe_oracle as vo
+    from tensorrl_qas_amd import qasm
+    from tensorrl_qas_amd.dmrg_to_qc import su4_to_qasm as sq
+    rng = np.random.default_rng(4)
+    n, layers = 5, 2
+    sites = so.brickwork_pairs(n, layers)
+    gates = so.random_unitaries(len(sites), rng)
+    text = sq.brickwork_to_qasm(n, sites, gates, rng)
+    nq, parsed = qasm.parse(text)
+    assert nq == n and sum(g.name == "cx" for g in parsed) == 3 * len(sites)
+    assert {g.name for g in parsed} <= {"rz", "ry", "cx"}
+    k, a, b, p, th = vo.qasm_to_gatelist([(g.name, list(g.qubits), g.angle) for g in parsed])
+    psi0 = np.zeros(1 << n, complex)
+    psi0[0] = 1
+    psi = vo.run_circuit(psi0, k, a, b, p, th)
+    ref = so.circuit_state(n, sites, gates)
+    rev = np.array([int(format(i, f"0{n}b")[::-1], 2) for i in range(1 << n)])
+    assert abs(abs(np.vdot(ref[rev], psi)) - 1) < 1e-9
+    # one block against its matrix, including the global phase-free comparison
+    U = gates[0]
+    ops = sq.decompose_su4(U, 0, 1, rng)
+    M = np.eye(4, dtype=complex)
+    for name, qs, ang in ops:
+        if name == "cx":
+            g = sq._CX_HI_LO
+        else:
+            one = sq._rz(ang) if name == "rz" else sq._ry(ang)
+            g = np.kron(one, np.eye(2)) if qs[0] == 0 else np.kron(np.eye(2), one)
+        M = g @ M
+    ph = np.vdot(U.reshape(-1), M.reshape(-1)) / 4
+    assert abs(abs(ph) - 1) < 1e-10 and np.max(np.abs(M - ph * U)) < 1e-9
