@@ -52,6 +52,7 @@ struct FitArgs {
   int off_u, off_e, off_red, off_sc, off_dn, off_lo, off_scratch, off_grp;
   const int* grp;         // [n_groups][2] first gate and size of every run of mutually disjoint gates
   int n_groups;
+  int red_slots;          // partial buffers of NW*64 doubles available in LDS (>= 2)
 };
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
@@ -523,11 +524,20 @@ __global__ __launch_bounds__(NT) void k_fit(FitArgs A) {
         const int first = grp_s[2 * gi], cnt = grp_s[2 * gi + 1];
         sweep_run<N, NT, 2>(psi, U, lo_s, first, cnt, true, tid);
         STAMP(3);
-        for (int k = first + cnt - 1; k >= first; --k, ++nenv) {
-          double* rb = red + (nenv & 1) * (NW * 64);  // double buffered: one barrier per gate
-          env_mfma<N, NT>(phi, psi, lo_s[k], rb, tid);
+        if (cnt <= A.red_slots) {
+          // one partial buffer per gate of the run: no barrier between the MFMA passes, the waves
+          // drift apart and hide each other's operand reads
+          for (int k = first; k < first + cnt; ++k) env_mfma<N, NT>(phi, psi, lo_s[k], red + (k - first) * (NW * 64), tid);
           __syncthreads();
-          if (tid < 16) E[k * kMat + tid] = env_mfma_combine<NT>(rb, tid);
+          if (tid < 16 * cnt) E[(first + (tid >> 4)) * kMat + (tid & 15)] = env_mfma_combine<NT>(red + (tid >> 4) * (NW * 64), tid & 15);
+          __syncthreads();
+        } else {
+          for (int k = first + cnt - 1; k >= first; --k, ++nenv) {
+            double* rb = red + (nenv & 1) * (NW * 64);  // double buffered: one barrier per gate
+            env_mfma<N, NT>(phi, psi, lo_s[k], rb, tid);
+            __syncthreads();
+            if (tid < 16) E[k * kMat + tid] = env_mfma_combine<NT>(rb, tid);
+          }
         }
         STAMP(2);
       }
@@ -816,7 +826,9 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
   size_t off = 2 * dim * 16;
   A.off_u = (int)off, off += (size_t)G * kMat * 16;
   A.off_e = (int)off, off += (size_t)G * kMat * 16;
-  A.off_red = (int)off, off += (size_t)2 * (NT / 64) * 64 * 8;  // double buffered (half-layer scheme)
+  A.off_red = (int)off;
+  const size_t red_off = off;
+  off += (size_t)2 * (NT / 64) * 64 * 8;  // double buffered (half-layer scheme)
   A.off_sc = (int)off, off += 2 * 16 * 8;  // one complex partial per wave (<= 16 waves)
   A.off_dn = (int)off, off += (size_t)((G + 1) & ~1) * 8;
   A.off_lo = (int)off, off += (size_t)((G + 3) & ~3) * 4;
@@ -824,6 +836,19 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
   const size_t scratch = (size_t)(NT / 16 < 16 ? NT / 16 : 16) * kSlotMats * kMat * 16;
   if (2 * dim * 16 >= scratch) A.off_scratch = 0;  // overlay on psi / phi, idle during the update
   else A.off_scratch = (int)off, off += scratch;
+  int red_slots = 2;
+  if (grouped && !getenv("MPS2QC_RED2")) {  // one partial buffer per gate of the largest run when LDS has room: moves everything behind red
+    int big = 2;
+    for (size_t g = 1; g < grp.size(); g += 2) big = grp[g] > big ? grp[g] : big;
+    const size_t extra = (size_t)(big - 2) * (NT / 64) * 64 * 8;
+    if (off + extra <= (size_t)kLdsLimit) {
+      red_slots = big;
+      off += extra;
+      A.off_sc += (int)extra, A.off_dn += (int)extra, A.off_lo += (int)extra, A.off_grp += (int)extra;
+      if (A.off_scratch) A.off_scratch += (int)extra;
+    }
+  }
+  (void)red_off;
   if (off > (size_t)kLdsLimit) {
     snprintf(g_err, sizeof g_err, "mps2qc_fit_brickwork: %d gates at %d qubits need %zu B of LDS (limit %d)", G, n,
              off, kLdsLimit);
@@ -870,7 +895,7 @@ int mps2qc_fit_brickwork(int device_id, int n, int G, const int32_t* sites, int 
   A.G = G, A.max_iter = max_iter, A.frozen = jit_frozen ? 1 : 0, A.use_mfma = use_mfma ? 1 : 0;
   A.target_shared = target_shared ? 1 : 0;
   A.beta1 = beta1, A.beta2 = beta2, A.eps = eps, A.tol = tol, A.param_tol = param_tol;
-  A.grp = d_grp, A.n_groups = (int)grp.size() / 2;
+  A.grp = d_grp, A.n_groups = (int)grp.size() / 2, A.red_slots = red_slots;
   A.lo = d_lo, A.lr_t = d_lr, A.target = d_t, A.init = d_init, A.final_g = d_fin, A.best_g = d_best;
   A.mom = d_m, A.vel = d_v, A.hist = d_hist, A.best_val = d_bv, A.n_iter = d_ni, A.envs = d_env, A.overlap = d_ov;
 

@@ -172,3 +172,34 @@ def test_fit_to_qasm_to_engine_state(tmp_path):
     assert abs(abs(np.vdot(ref[rev], state)) - 1) < 1e-9
     assert abs((1 - abs(np.vdot(psi_t, state))) - so.loss(n, list(sites), gates, target)) < 1e-9
     assert 1 - abs(np.vdot(psi_t, state)) < np.min(opt.best_val) + 1e-2
+
+
+@pytest.mark.parametrize("n", [6, 12])
+def test_arbitrary_gate_sequences(n):
+    """Gate lists that are not brickwork: a staircase (every run of disjoint gates has one gate),
+    a single gate, and runs whose paired gates are far apart / in descending order."""
+    from tensorrl_qas_amd import dmrg_to_qc as dq
+    rng = np.random.default_rng(n)
+    for sites in ([0, 1, 2, 3, 4], [n - 2], [n - 2, 0, 2, 1, n - 3, 0], [0, n - 2, 2, 1, 3, 0]):
+        sites = np.array(sites, np.int32)
+        G = len(sites)
+        v = rng.normal(size=1 << n) + 1j * rng.normal(size=1 << n)
+        tg = v / np.linalg.norm(v)
+        init = np.array([so.random_unitaries(G, rng) for _ in range(2)])
+        opt = dq.StiefelAdam(3e-3, 0.9, 0.999, 1e-8)
+        opt.minimize(dq.BrickworkOverlap(n, sites, tg), init, max_iter=3, tol=1e-30, param_tol=0.0)
+        for b in range(2):
+            ref = so.StiefelAdam(3e-3, 0.9, 0.999, 1e-8)
+            ref.init(init[b])
+            bv, bp, hist, fin = ref.minimize(n, list(sites), tg, init[b], max_iter=3, tol=1e-30, param_tol=0.0)
+            assert np.max(np.abs(np.array(opt.loss_history[b]) - np.array(hist))) < 1e-12
+            assert np.max(np.abs(opt.final_params[b] - np.array(fin))) < 1e-11
+            o, envs = so.overlap_and_envs(n, list(sites), list(fin_prev(ref, n, sites, tg, init[b])), tg)
+            assert np.max(np.abs(opt.last_envs[b] - np.array(envs))) < 1e-11
+
+
+def fin_prev(ref, n, sites, tg, init):
+    """Gates before the last of 3 steps (the environments the kernel reports belong to them)."""
+    r2 = so.StiefelAdam(ref.learning_rate, ref.beta1, ref.beta2, ref.eps)
+    r2.init(init)
+    return r2.minimize(n, list(sites), tg, init, max_iter=2, tol=1e-30, param_tol=0.0)[3]
