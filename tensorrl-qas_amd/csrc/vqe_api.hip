@@ -74,7 +74,7 @@ struct vqe_handle {
   std::vector<int32_t> h_par_count;
   DevBuf<GateRec> d_gates;
   DevBuf<int64_t> d_gate_begin, d_par_begin, d_scratch_begin;
-  DevBuf<int32_t> d_gate_count, d_par_count, d_nfev, d_new_gate;
+  DevBuf<int32_t> d_gate_count, d_par_count, d_nfev, d_new_gate, d_order;
   bool has_new_gate = false;
   std::vector<int32_t> h_gate_count;
   DevBuf<double> d_theta, d_x, d_xraw, d_f, d_scratch;
@@ -414,6 +414,7 @@ BatchArgs make_args(vqe_t* h) {
   A.gate_count = h->d_gate_count.p;
   A.par_begin = h->d_par_begin.p;
   A.par_count = h->d_par_count.p;
+  A.order = h->d_order.p;
   A.theta = h->d_theta.p;
   A.xout = h->d_x.p;
   A.xraw = h->d_xraw.p;
@@ -444,6 +445,7 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   std::vector<int64_t> sbeg(batch);
   int64_t stot = 0;
   int max_ops = 1, max_par = 1;
+  std::vector<double> cost(batch);
   for (int b = 0; b < batch; ++b) {
     sbeg[b] = stot;
     stot += (int64_t)cby::scratch_doubles(pcnt[b], 16);   // the larger of the device contexts' paddings
@@ -455,12 +457,24 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
       ops += (k == G_CNOT) ? 0 : (k == G_DEPOL2 ? 2 : 1);
     }
     max_ops = std::max(max_ops, ops);
+    // expected cycles of one evaluation of the fused kernel beyond the constant energy step:
+    // ~1.3 k per simulated op, ~22 per squared parameter for the optimiser update
+    double ca = 1300.0, cb = 22.0, cc = 0.0;
+    if (const char* e = getenv("VQE_LPT_COEF")) sscanf(e, "%lf,%lf,%lf", &ca, &cb, &cc);   // experiments
+    cost[b] = ca * ops + cb * (double)pcnt[b] * (double)pcnt[b] + cc * (double)pcnt[b];
   }
+  // workgroup i runs circuit order[i], longest first: the hardware hands workgroups to free CU
+  // slots in index order, so the short circuits fill the end of the launch
+  std::vector<int32_t> order(batch);
+  for (int b = 0; b < batch; ++b) order[b] = b;
+  if (!getenv("VQE_NO_LPT"))   // experiments: launch in caller order
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[x] > cost[y]; });
   if ((rc = upload(h, h->d_gates, gates.data(), gates.size()))) return rc;
   if ((rc = upload(h, h->d_gate_begin, gbeg.data(), gbeg.size()))) return rc;
   if ((rc = upload(h, h->d_gate_count, gcnt.data(), gcnt.size()))) return rc;
   if ((rc = upload(h, h->d_par_begin, pbeg.data(), pbeg.size()))) return rc;
   if ((rc = upload(h, h->d_par_count, pcnt.data(), pcnt.size()))) return rc;
+  if ((rc = upload(h, h->d_order, order.data(), order.size()))) return rc;
   if ((rc = upload(h, h->d_scratch_begin, sbeg.data(), sbeg.size()))) return rc;
   if ((rc = upload(h, h->d_theta, theta0, (size_t)total_params))) return rc;
   HIP_TRY(h, h->d_scratch.reserve((size_t)stot + 2));

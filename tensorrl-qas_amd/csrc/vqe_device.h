@@ -108,6 +108,7 @@ struct BatchArgs {
   const int32_t* gate_count;   // [batch]
   const int64_t* par_begin;    // [batch]
   const int32_t* par_count;    // [batch]
+  const int32_t* order;        // [batch] circuit run by workgroup i: longest expected first (LPT), shortens the launch tail
   const double* theta;         // [sum P] in: theta / x0 (never written: runs are repeatable)
   double* xout;                // [sum P] out: optimised parameters (minimize / env_step)
   double* xraw;                // [sum P] out: the same before the float32 rounding of env_step
@@ -1340,7 +1341,7 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
   constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
-  const int b = blockIdx.x;
+  const int b = A.order[blockIdx.x];
   const int P = A.par_count[b];
   const double* theta = A.theta + A.par_begin[b];
   double* xout = A.xout + A.par_begin[b];

@@ -174,6 +174,30 @@ def test_batch_of_circuits(tq):
             assert nfev[b] == 1
 
 
+def test_launch_order_does_not_change_results(tq, monkeypatch):
+    """The fused kernel runs the circuits longest-expected-first (workgroup i -> circuit order[i]);
+    every output stays at its circuit's index and is bit-identical to the caller-order launch."""
+    n = 10
+    rng = np.random.default_rng(17)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 60, rng)
+    circs, ths = [], []
+    for b in range(40):
+        g = random_gates(n, int(rng.integers(0, 40)), rng)
+        circs.append(tq.Circuit(*g[:4], g[4].size))
+        ths.append(g[4])
+    out = []
+    for no_lpt in (False, True):
+        if no_lpt:
+            monkeypatch.setenv("VQE_NO_LPT", "1")
+        eng = _engine(tq, n, psi0, ham)
+        eng.batch_load(circs, ths)
+        eng.batch_run_minimize(1.0, 1e-4, 150)
+        out.append(eng.batch_fetch())
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("n,G,seed", [(14, 24, 0), (15, 10, 1), (17, 8, 2), (18, 6, 3)])
 def test_streaming_path(tq, n, G, seed):
     rng = np.random.default_rng(300 + seed)
