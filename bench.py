@@ -106,7 +106,7 @@ def cpu_baseline(tq, ham, psi0, batch, G, n_steps, maxfun):
             "evals_per_s": evals / dt}
 
 
-def episode_aux(tq, torch, dev, num_envs, max_steps):
+def episode_aux(tq, torch, dev, num_envs, max_steps, barrier=None, seed0=0):
     """The named configuration itself: TensorRL_fixed/LIH12q_TNbond2 (137 layers, 110 steps per
     episode, COBYLA maxiter 1000) through VecCircuitEnv with a uniformly random legal policy -
     warm-started COBYLA exactly as in the reference's episodes.  Data are the synthetic LiH-12q
@@ -123,10 +123,10 @@ def episode_aux(tq, torch, dev, num_envs, max_steps):
     # two half batches, software pipelined: the host bookkeeping of one overlaps the launch of
     # the other (VecCircuitEnv.step_async / step_wait; each half has its own engine and stream)
     half = max(1, num_envs // 2)
-    vecs = [VecCircuitEnv(CircuitEnv, conf, torch.device(f"cuda:{dev}"), half, seed=s) for s in (0, 1)]
+    vecs = [VecCircuitEnv(CircuitEnv, conf, torch.device(f"cuda:{dev}"), half, seed=s) for s in (seed0, seed0 + 1)]
     num_envs = 2 * half
     table = vecs[0].envs[0]._actions_table
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(7 + seed0)
     for v in vecs:
         v.reset()
     n_steps = min(max_steps, vecs[0].envs[0].num_layers_termination)
@@ -150,6 +150,9 @@ def episode_aux(tq, torch, dev, num_envs, max_steps):
         steps += vec.num_envs
         nfev += sum(e.nfev for e in vec.envs)
 
+    if barrier is not None:      # tools/probe_episode_procs.py: several host processes share the GPU
+        barrier.wait()
+    t_start = time.time()
     t0 = time.perf_counter()
     vecs[0].step_async(choose(vecs[0]))
     for it in range(n_steps):
@@ -163,6 +166,7 @@ def episode_aux(tq, torch, dev, num_envs, max_steps):
     return {"workload": f"TensorRL_fixed/LIH12q_TNbond2 (synthetic data), 2 x {half} envs x {n_steps} steps, random policy, "
                         "half batches pipelined (step_async / step_wait)",
             "env_steps_per_s_wall": steps / dt, "env_steps_per_s_device": steps / t_gpu,
+            "env_steps": steps, "t_start": t_start, "t_end": t_start + dt,
             "device_note": "sum of the kernel times of both halves; their launches may overlap on the GPU",
             "mean_nfev_per_step": nfev / steps, "mean_rotations_at_end": float(np.mean(
                 [int((e.state[:, 12:15] == 1).sum()) for e in envs]))}
