@@ -104,3 +104,33 @@ class TermShardedEngine:
             self.engine.batch_load([circuit], [x])
             return float(self.partial_energies()[0])
         return sharded_minimize(partial, x0, rhobeg, rhoend, maxfun)
+
+
+def fit_restarts_sharded(fit_shard, n_restarts_total: int, group=None):
+    """Random restarts of the MPS -> PQC fit spread over the ranks (independent units, replicas
+    only): every rank fits its contiguous share of the restart ids and ONE all-gather of the
+    best losses (8 bytes per rank) picks the winner, whose gates are broadcast.
+
+    ``fit_shard(restart_ids: range) -> (best_val: float, gates: ndarray[G,4,4] complex)`` runs
+    this rank's restarts (on the GPU: ``dmrg_to_qc.mps_to_qc(..., n_restarts=len(ids))`` with a
+    generator seeded per restart id, so the result does not depend on the world size).
+    Returns ``(best_val, gates, owner_rank)``, identical on all ranks; ties go to the lowest rank."""
+    import torch
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if on else 0
+    world = dist.get_world_size(group) if on else 1
+    ids = env_shard(n_restarts_total, rank, world)
+    val, gates = fit_shard(ids) if len(ids) else (float("inf"), None)
+    if world == 1:
+        return float(val), gates, 0
+    vals = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(vals, torch.tensor([float(val)], dtype=torch.float64), group=group)
+    owner = int(np.argmin([float(v[0]) for v in vals]))
+    shape = torch.tensor(list(np.shape(gates)) if rank == owner else [0, 0, 0], dtype=torch.int64)
+    dist.broadcast(shape, src=owner, group=group)
+    buf = torch.zeros(tuple(int(s) for s in shape) + (2,), dtype=torch.float64)
+    if rank == owner:
+        buf.copy_(torch.view_as_real(torch.as_tensor(np.ascontiguousarray(gates, np.complex128))))
+    dist.broadcast(buf, src=owner, group=group)
+    return float(vals[owner][0]), torch.view_as_complex(buf).numpy().copy(), owner

@@ -44,7 +44,15 @@ def _worker(rank, world, port, out):
     envs = list(parallel.env_shard(11, rank, world))
     counts = torch.tensor([int(mine.sum())])
     dist.all_reduce(counts)
-    out[rank] = dict(total=float(tot[0]), full=full, x=x.tolist(), f=f, nfev=nfev, envs=envs,
+    # restarts of the MPS -> PQC fit sharded over ranks; a stand-in "fit" (loss and gates are a pure
+    # function of the restart id) checks the selection logic without a GPU
+    def fit_shard(ids):
+        losses = {i: ((i * 37) % 11) / 11.0 + 0.01 * i for i in ids}
+        best = min(losses, key=losses.get)
+        return losses[best], np.full((3, 4, 4), best + 1j * best)
+
+    fv, fg, fo = parallel.fit_restarts_sharded(fit_shard, 7)
+    out[rank] = dict(fit_val=fv, fit_gate=complex(fg[0, 0, 0]), fit_owner=fo, total=float(tot[0]), full=full, x=x.tolist(), f=f, nfev=nfev, envs=envs,
                      covered=int(counts[0]), n_terms=len(xs), groups_split=bool(
                          len(set(xs[mine].tolist()) & set(xs[~mine].tolist()))))
     dist.destroy_process_group()
@@ -61,6 +69,11 @@ def test_term_and_env_sharding_two_ranks():
     assert r0["x"] == r1["x"] and r0["nfev"] == r1["nfev"] and r0["f"] == r1["f"]      # lock-step
     assert r0["f"] <= r0["full"] + 1e-12
     assert sorted(r0["envs"] + r1["envs"]) == list(range(11)) and abs(len(r0["envs"]) - len(r1["envs"])) <= 1
+    losses = {i: ((i * 37) % 11) / 11.0 + 0.01 * i for i in range(7)}
+    best = min(losses, key=losses.get)
+    for r in (r0, r1):      # the global best restart, identical on both ranks
+        assert r["fit_val"] == losses[best] and r["fit_gate"] == best + 1j * best
+    assert r0["fit_owner"] == r1["fit_owner"] == (0 if best < 4 else 1)
 
 
 def test_term_owner_partitions():
