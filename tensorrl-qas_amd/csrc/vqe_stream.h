@@ -2,7 +2,7 @@
 //
 // Every evaluation stream keeps its 2^n complex128 amplitudes in HBM (16 MiB at n = 20).
 // The same affine GF(2) bookkeeping as the LDS path removes every CNOT; each remaining
-// rotation is one coalesced read-modify-write sweep (32 * 2^n bytes).  The energy kernel
+// rotations are applied two per coalesced read-modify-write sweep (32 * 2^n bytes per sweep).  The energy kernel
 // transforms the Pauli masks into the physical layout instead of permuting the state, reads
 // each amplitude once plus one partner amplitude per X-mask group, evaluates the sign sums
 // on the fly and reduces per block; a second tiny kernel sums the block partials in a fixed
@@ -107,46 +107,77 @@ __global__ void __launch_bounds__(kThreads) k_s_init(BatchArgs A, double2* state
   if (p < dim) states[(size_t)blockIdx.y * dim + p] = A.init[p];
 }
 
-// op number `o` of every stream: one pair (or two neighbouring amplitudes) per thread
-__global__ void __launch_bounds__(kThreads) k_s_op(BatchArgs A, double2* states, const Op* ops,
-                                                   const int32_t* meta, const double2* cs, int o) {
-  const int b = blockIdx.y;
-  if (o >= meta[(size_t)b * 8]) return;
-  const Op op = ops[(size_t)b * A.max_ops + o];
+// One op on the four amplitudes v[e] at indices idx[e] = p0 ^ (e&1 ? g1 : 0) ^ (e&2 ? g2 : 0).  Every
+// update is written per element (new[e] = c a[e] + s(e) a[partner]), so the roles of the two
+// members of a pair need no case distinction: parity(xm & zm) = 1 makes s(partner) = -s(e).
+__device__ __forceinline__ void s_apply(double2 (&v)[4], const uint32_t (&idx)[4], const Op op, const double2* csb,
+                                        uint32_t g1, uint32_t g2) {
   const int kind = op.kind & 0xff, inv = (op.kind >> 8) & 1;
-  const size_t dim = (size_t)1 << A.n;
-  double2* psi = states + (size_t)b * dim;
-  const uint32_t q = blockIdx.x * kThreads + threadIdx.x;
-  if (q >= dim / 2) return;
   if (kind == OP_RX || kind == OP_RY) {
-    const double2 c = cs[(size_t)b * A.max_params + op.pidx];
-    const int hb = 31 - __clz((int)op.xm);
-    const uint32_t p0 = insert0(q, hb), p1 = p0 ^ op.xm;
-    const double2 a0 = psi[p0], a1 = psi[p1];
-    if (kind == OP_RX) {
-      psi[p0] = make_double2(c.x * a0.x - c.y * a1.y, c.x * a0.y + c.y * a1.x);
-      psi[p1] = make_double2(c.x * a1.x - c.y * a0.y, c.x * a1.y + c.y * a0.x);
-    } else {
-      const double s0 = (parity32(p0 & op.zm) ^ inv) ? -c.y : c.y;
-      psi[p0] = make_double2(c.x * a0.x + s0 * a1.x, c.x * a0.y + s0 * a1.y);
-      psi[p1] = make_double2(c.x * a1.x - s0 * a0.x, c.x * a1.y - s0 * a0.y);
+    const double2 c = csb[op.pidx];
+    const int flip = op.xm == g1 ? 1 : (op.xm == g2 ? 2 : 3);
+    double2 w[4];
+#define S_PAIR(F)                                                                                  \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
+      const double2 a = v[e], bq = v[e ^ (F)];                                                      \
+      if (kind == OP_RX) w[e] = make_double2(c.x * a.x - c.y * bq.y, c.x * a.y + c.y * bq.x);      \
+      else {                                                                                       \
+        const double sg = (parity32(idx[e] & op.zm) ^ inv) ? -c.y : c.y;                           \
+        w[e] = make_double2(c.x * a.x + sg * bq.x, c.x * a.y + sg * bq.y);                          \
+      }                                                                                            \
     }
-  } else if (kind == OP_RZ) {
-    const double2 c = cs[(size_t)b * A.max_params + op.pidx];
+    if (flip == 1) { S_PAIR(1) } else if (flip == 2) { S_PAIR(2) } else { S_PAIR(3) }
+#undef S_PAIR
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const uint32_t p = 2 * q + k;
-      const double s = (parity32(p & op.zm) ^ inv) ? -c.y : c.y;
-      const double2 a = psi[p];
-      psi[p] = make_double2(c.x * a.x - s * a.y, c.x * a.y + s * a.x);
+    for (int e = 0; e < 4; ++e) v[e] = w[e];
+  } else if (kind == OP_RZ) {
+    const double2 c = csb[op.pidx];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double sg = (parity32(idx[e] & op.zm) ^ inv) ? -c.y : c.y;
+      const double2 a = v[e];
+      v[e] = make_double2(c.x * a.x - sg * a.y, c.x * a.y + sg * a.x);
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const uint32_t p = 2 * q + k;
-      if (parity32(p & op.zm) ^ inv) { const double2 a = psi[p]; psi[p] = make_double2(-a.x, -a.y); }
-    }
+    for (int e = 0; e < 4; ++e)
+      if (parity32(idx[e] & op.zm) ^ inv) v[e] = make_double2(-v[e].x, -v[e].y);
   }
+}
+
+// ops number `o` and `o + 1` of every stream in ONE read-modify-write sweep: a thread owns the four
+// amplitudes closed under both partner masks (half the HBM traffic of one sweep per op).
+__global__ void __launch_bounds__(kThreads) k_s_op2(BatchArgs A, double2* states, const Op* ops,
+                                                    const int32_t* meta, const double2* cs, int o) {
+  const int b = blockIdx.y;
+  const int nops = meta[(size_t)b * 8];
+  if (o >= nops) return;
+  const Op op1 = ops[(size_t)b * A.max_ops + o];
+  const bool two = o + 1 < nops;
+  const Op op2 = two ? ops[(size_t)b * A.max_ops + o + 1] : op1;
+  const size_t dim = (size_t)1 << A.n;
+  double2* psi = states + (size_t)b * dim;
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= dim / 4) return;
+  auto pairing = [](const Op& op) { const int k = op.kind & 0xff; return (k == OP_RX || k == OP_RY) ? op.xm : 0u; };
+  const uint32_t x1 = pairing(op1), x2 = two ? pairing(op2) : 0u;
+  uint32_t g1, g2;
+  if (x1 == 0 && x2 == 0) { g1 = 1u; g2 = 2u; }
+  else if (x1 == 0 || x2 == 0 || x1 == x2) { g1 = x1 ? x1 : x2; g2 = g1 == 1u ? 2u : 1u; }
+  else { g1 = x1; g2 = x2; }
+  const int hb1 = 31 - __clz((int)g1);
+  if ((g2 >> hb1) & 1u) g2 ^= g1;            // echelon form: only g1 has bit hb1
+  const int hb2 = 31 - __clz((int)g2);
+  const uint32_t p0 = hb1 < hb2 ? insert0(insert0(t, hb1), hb2) : insert0(insert0(t, hb2), hb1);
+  const uint32_t idx[4] = {p0, p0 ^ g1, p0 ^ g2, p0 ^ g1 ^ g2};
+  double2 v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = psi[idx[e]];
+  const double2* csb = cs + (size_t)b * A.max_params;
+  s_apply(v, idx, op1, csb, g1, g2);
+  if (two) s_apply(v, idx, op2, csb, g1, g2);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) psi[idx[e]] = v[e];
 }
 
 // Pauli masks of the Hamiltonian expressed in each stream's physical layout.
@@ -285,8 +316,8 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
     hipLaunchKernelGGL(k_s_compile, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.masks, sw.meta, eval_id);
     hipLaunchKernelGGL(k_s_sincos, dim3((A.max_params + 63) / 64, B), dim3(64), 0, st, A, sw.cs);
     hipLaunchKernelGGL(k_s_init, dim3((unsigned)(dim / kThreads), B), dim3(kThreads), 0, st, A, sw.states);
-    for (int o = 0; o < A.max_ops; ++o)
-      hipLaunchKernelGGL(k_s_op, dim3((unsigned)(dim / 2 / kThreads), B), dim3(kThreads), 0, st, A, sw.states,
+    for (int o = 0; o < A.max_ops; o += 2)   // two ops per sweep
+      hipLaunchKernelGGL(k_s_op2, dim3((unsigned)(dim / 4 / kThreads), B), dim3(kThreads), 0, st, A, sw.states,
                          sw.ops, sw.meta, sw.cs, o);
   }
   if (want_energy) {
