@@ -2,7 +2,8 @@
 //
 // Every evaluation stream keeps its 2^n complex128 amplitudes in HBM (16 MiB at n = 20).
 // The same affine GF(2) bookkeeping as the LDS path removes every CNOT; each remaining
-// rotations are applied two per coalesced read-modify-write sweep (32 * 2^n bytes per sweep).  The energy kernel
+// rotations are applied kOpsPerSweep at a time per coalesced read-modify-write sweep (32 * 2^n bytes
+// per sweep).  The energy kernel
 // transforms the Pauli masks into the physical layout instead of permuting the state, reads
 // each amplitude once plus one partner amplitude per X-mask group, evaluates the sign sums
 // on the fly and reduces per block; a second tiny kernel sums the block partials in a fixed
@@ -107,78 +108,161 @@ __global__ void __launch_bounds__(kThreads) k_s_init(BatchArgs A, double2* state
   if (p < dim) states[(size_t)blockIdx.y * dim + p] = A.init[p];
 }
 
-// One op on the four amplitudes v[e] at indices idx[e] = p0 ^ (e&1 ? g1 : 0) ^ (e&2 ? g2 : 0).  Every
-// update is written per element (new[e] = c a[e] + s(e) a[partner]), so the roles of the two
-// members of a pair need no case distinction: parity(xm & zm) = 1 makes s(partner) = -s(e).
-__device__ __forceinline__ void s_apply(double2 (&v)[4], const uint32_t (&idx)[4], const Op op, const double2* csb,
-                                        uint32_t g1, uint32_t g2) {
+// ---- K ops per sweep ---------------------------------------------------------------------------
+// A thread owns the 2^K amplitudes p0 ^ span(g[0..K-1]).  Slot j of the basis belongs to op j of
+// the group: g[j] = its partner mask when that is independent of the earlier slots (the normal
+// case: pairs e <-> e ^ (1 << j), static register indices), otherwise a filler unit vector; an op
+// whose mask depends on the other slots (rare) takes the generic path with a computed flip code.
+// p0 runs over the coset representatives with the pivot bits of the reduced basis cleared.  Every
+// update is written per element (new[e] = c a[e] + s(e) a[partner]): parity(xm & zm) = 1 makes
+// s(partner) = -s(e), so the two members of a pair need no case distinction.
+template <int K>
+__device__ __forceinline__ void s_apply_k(double2 (&v)[1 << K], const uint32_t (&idx)[1 << K], const Op op,
+                                          const double2* csb, const int slot, const int flip) {
+  constexpr int E = 1 << K;
   const int kind = op.kind & 0xff, inv = (op.kind >> 8) & 1;
   if (kind == OP_RX || kind == OP_RY) {
     const double2 c = csb[op.pidx];
-    const int flip = op.xm == g1 ? 1 : (op.xm == g2 ? 2 : 3);
-    double2 w[4];
-#define S_PAIR(F)                                                                                  \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
-      const double2 a = v[e], bq = v[e ^ (F)];                                                      \
-      if (kind == OP_RX) w[e] = make_double2(c.x * a.x - c.y * bq.y, c.x * a.y + c.y * bq.x);      \
-      else {                                                                                       \
-        const double sg = (parity32(idx[e] & op.zm) ^ inv) ? -c.y : c.y;                           \
-        w[e] = make_double2(c.x * a.x + sg * bq.x, c.x * a.y + sg * bq.y);                          \
-      }                                                                                            \
-    }
-    if (flip == 1) { S_PAIR(1) } else if (flip == 2) { S_PAIR(2) } else { S_PAIR(3) }
-#undef S_PAIR
+    double2 w[E];
+    bool done = false;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = w[e];
+    for (int i = 0; i < K; ++i)      // own slot, or the mask of another slot (two rotations on one qubit)
+      if (flip == (1 << i)) {
+        done = true;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double2 a = v[e], bq = v[e ^ (1 << i)];
+          if (kind == OP_RX) w[e] = make_double2(c.x * a.x - c.y * bq.y, c.x * a.y + c.y * bq.x);
+          else {
+            const double sg = (parity32(idx[e] & op.zm) ^ inv) ? -c.y : c.y;
+            w[e] = make_double2(c.x * a.x + sg * bq.x, c.x * a.y + sg * bq.y);
+          }
+        }
+      }
+    if (!done) {   // dependent mask: dynamic partner index (scratch), wave-uniform and rare
+      double2 tmp[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) tmp[e] = v[e];
+      for (int e = 0; e < E; ++e) {
+        const double2 a = tmp[e], bq = tmp[e ^ flip];
+        if (kind == OP_RX) w[e] = make_double2(c.x * a.x - c.y * bq.y, c.x * a.y + c.y * bq.x);
+        else {
+          const double sg = (parity32(idx[e] & op.zm) ^ inv) ? -c.y : c.y;
+          w[e] = make_double2(c.x * a.x + sg * bq.x, c.x * a.y + sg * bq.y);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = w[e];
   } else if (kind == OP_RZ) {
     const double2 c = csb[op.pidx];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < E; ++e) {
       const double sg = (parity32(idx[e] & op.zm) ^ inv) ? -c.y : c.y;
       const double2 a = v[e];
       v[e] = make_double2(c.x * a.x - sg * a.y, c.x * a.y + sg * a.x);
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < E; ++e)
       if (parity32(idx[e] & op.zm) ^ inv) v[e] = make_double2(-v[e].x, -v[e].y);
   }
 }
 
-// ops number `o` and `o + 1` of every stream in ONE read-modify-write sweep: a thread owns the four
-// amplitudes closed under both partner masks (half the HBM traffic of one sweep per op).
-__global__ void __launch_bounds__(kThreads) k_s_op2(BatchArgs A, double2* states, const Op* ops,
+template <int K>
+__global__ void __launch_bounds__(kThreads) k_s_opk(BatchArgs A, double2* states, const Op* ops,
                                                     const int32_t* meta, const double2* cs, int o) {
+  constexpr int E = 1 << K;
   const int b = blockIdx.y;
   const int nops = meta[(size_t)b * 8];
   if (o >= nops) return;
-  const Op op1 = ops[(size_t)b * A.max_ops + o];
-  const bool two = o + 1 < nops;
-  const Op op2 = two ? ops[(size_t)b * A.max_ops + o + 1] : op1;
+  const int cnt = nops - o < K ? nops - o : K;
   const size_t dim = (size_t)1 << A.n;
   double2* psi = states + (size_t)b * dim;
   const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
-  if (t >= dim / 4) return;
-  auto pairing = [](const Op& op) { const int k = op.kind & 0xff; return (k == OP_RX || k == OP_RY) ? op.xm : 0u; };
-  const uint32_t x1 = pairing(op1), x2 = two ? pairing(op2) : 0u;
-  uint32_t g1, g2;
-  if (x1 == 0 && x2 == 0) { g1 = 1u; g2 = 2u; }
-  else if (x1 == 0 || x2 == 0 || x1 == x2) { g1 = x1 ? x1 : x2; g2 = g1 == 1u ? 2u : 1u; }
-  else { g1 = x1; g2 = x2; }
-  const int hb1 = 31 - __clz((int)g1);
-  if ((g2 >> hb1) & 1u) g2 ^= g1;            // echelon form: only g1 has bit hb1
-  const int hb2 = 31 - __clz((int)g2);
-  const uint32_t p0 = hb1 < hb2 ? insert0(insert0(t, hb1), hb2) : insert0(insert0(t, hb2), hb1);
-  const uint32_t idx[4] = {p0, p0 ^ g1, p0 ^ g2, p0 ^ g1 ^ g2};
-  double2 v[4];
+  if (t >= dim >> K) return;
+  Op op[K];
+  uint32_t g[K], red[K];       // slot masks; the same span in reduced echelon form
+  int hbit[K], flip[K];
+  uint32_t pivots = 0;
+  int nred = 0;
+  auto reduce = [&](uint32_t x) {   // x modulo the span collected so far
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = psi[idx[e]];
+    for (int i = 0; i < K; ++i) if (i < nred && ((x >> hbit[i]) & 1u)) x ^= red[i];
+    return x;
+  };
+  auto push = [&](uint32_t x) {     // x != 0 reduced: new basis vector, keep the others reduced
+    const int h = 31 - __clz((int)x);
+#pragma unroll
+    for (int i = 0; i < K; ++i) if (i < nred && ((red[i] >> h) & 1u)) red[i] ^= x;
+#pragma unroll
+    for (int i = 0; i < K; ++i) if (i == nred) { red[i] = x; hbit[i] = h; }
+    pivots |= 1u << h;
+    ++nred;
+  };
+  // pass 1: independent partner masks take their own slot
+  bool own[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    own[j] = false;
+    g[j] = 0;
+    flip[j] = 0;
+    if (j < cnt) {
+      op[j] = ops[(size_t)b * A.max_ops + o + j];
+      const int k = op[j].kind & 0xff;
+      if (k == OP_RX || k == OP_RY) {
+        const uint32_t r = reduce(op[j].xm);
+        if (r) { push(r); g[j] = op[j].xm; own[j] = true; flip[j] = 1 << j; }
+      }
+    }
+  }
+  // pass 2: fillers for the other slots
+  {
+    int q = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (!own[j]) {
+        uint32_t r = 0;
+        while ((r = reduce(1u << q)) == 0) ++q;
+        push(r);
+        g[j] = 1u << q;
+        ++q;
+      }
+  }
+  // pass 3: flip codes of the dependent partner masks (brute force over the 2^K - 1 combinations)
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+    if (j < cnt && !own[j]) {
+      const int k = op[j].kind & 0xff;
+      if (k == OP_RX || k == OP_RY)
+        for (int f = 1; f < E; ++f) {
+          uint32_t x = 0;
+#pragma unroll
+          for (int i = 0; i < K; ++i) if ((f >> i) & 1) x ^= g[i];
+          if (x == op[j].xm) flip[j] = f;
+        }
+    }
+  // coset representative: zeros inserted at the pivot bits, lowest first
+  uint32_t p0 = t;
+  for (int q = 0; q < A.n; ++q) if ((pivots >> q) & 1u) p0 = insert0(p0, q);
+  uint32_t idx[E];
+  double2 v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    uint32_t x = p0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) if ((e >> i) & 1) x ^= g[i];
+    idx[e] = x;
+    v[e] = psi[x];
+  }
   const double2* csb = cs + (size_t)b * A.max_params;
-  s_apply(v, idx, op1, csb, g1, g2);
-  if (two) s_apply(v, idx, op2, csb, g1, g2);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) psi[idx[e]] = v[e];
+  for (int j = 0; j < K; ++j) if (j < cnt) s_apply_k<K>(v, idx, op[j], csb, j, flip[j]);
+#pragma unroll
+  for (int e = 0; e < E; ++e) psi[idx[e]] = v[e];
 }
+
+constexpr int kOpsPerSweep = 4;
 
 // Pauli masks of the Hamiltonian expressed in each stream's physical layout.
 __global__ void k_s_terms(BatchArgs A, const uint32_t* masks, const int32_t* meta, int n_terms,
@@ -316,9 +400,9 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
     hipLaunchKernelGGL(k_s_compile, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.masks, sw.meta, eval_id);
     hipLaunchKernelGGL(k_s_sincos, dim3((A.max_params + 63) / 64, B), dim3(64), 0, st, A, sw.cs);
     hipLaunchKernelGGL(k_s_init, dim3((unsigned)(dim / kThreads), B), dim3(kThreads), 0, st, A, sw.states);
-    for (int o = 0; o < A.max_ops; o += 2)   // two ops per sweep
-      hipLaunchKernelGGL(k_s_op2, dim3((unsigned)(dim / 4 / kThreads), B), dim3(kThreads), 0, st, A, sw.states,
-                         sw.ops, sw.meta, sw.cs, o);
+    for (int o = 0; o < A.max_ops; o += kOpsPerSweep)
+      hipLaunchKernelGGL(k_s_opk<kOpsPerSweep>, dim3((unsigned)((dim >> kOpsPerSweep) / kThreads), B), dim3(kThreads), 0, st,
+                         A, sw.states, sw.ops, sw.meta, sw.cs, o);
   }
   if (want_energy) {
     const int m = std::max(nt, ng);
