@@ -273,7 +273,16 @@ def heis20_aux(tq, torch, dist, rank, world, dev, steps):
     t = torch.tensor([dt, dr], dtype=torch.float64, device=f"cuda:{dev}")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return {"workload": "heisenberg_20q_77terms_G32_B256_sharded", "evals_per_s": B * steps / float(t[0].item()),
+    # algorithmic bytes of one evaluation: 2^n * 16 * (2 G_rot + T_x), G_rot = mean rotations per circuit
+    g_rot = float(np.count_nonzero(batch["kind"])) / B
+    bytes_per_eval = (1 << n) * 16 * (2 * g_rot + 20)
+    evals_s = B * steps / float(t[0].item())
+    return {"workload": "heisenberg_20q_77terms_G32_B256_sharded", "evals_per_s": evals_s,
+            "roofline": {"bound": "hbm", "achieved": bytes_per_eval * evals_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bytes_per_eval * evals_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_eval": bytes_per_eval, "mean_rotations": g_rot,
+                         "note": "all ranks together; four ops share one read-modify-write sweep of the state (DESIGN 4.3), "
+                                 "so fewer bytes move than the per-gate figure counts: frac may exceed 1"},
             "reduction_ms_per_batch": float(t[1].item()) / steps * 1e3,
             "reduction_evals_per_s": B * steps / float(t[1].item()),
             "x_groups_total": 20, "sharding": "amplitude slices of the term sum, 1 all-reduce", "energy_checksum": float(e.sum().item()), "scaling": "strong"}
