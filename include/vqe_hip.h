@@ -57,6 +57,10 @@ int vqe_create(int n_qubits, int device_id, vqe_t** out);
 void vqe_destroy(vqe_t* h);
 const char* vqe_last_error(const vqe_t* h); /* h may be NULL: last error of vqe_create */
 int vqe_set_stream(vqe_t* h, void* hip_stream); /* NULL: the handle's own stream */
+/* the stream all work of the handle is issued on (its own one unless vqe_set_stream replaced it):
+ * lets the caller order its own streams against it (e.g. torch.cuda.ExternalStream + wait_stream
+ * before an RCCL all-reduce of vqe_batch_copy_energy's destination) */
+int vqe_get_stream(vqe_t* h, void** hip_stream);
 int vqe_sync(vqe_t* h);
 /* device facts for the caller's roofline arithmetic: [0]=CU count, [1]=LDS bytes/CU,
  * [2]=workgroups resident per CU for the last LDS-path launch, [3]=1 if the LDS-resident
@@ -132,7 +136,12 @@ int vqe_batch_run_reduction(vqe_t* h);
  * that gate from x0 = theta0 (the reference optimises the pre-action state, :453); the
  * optimum is rounded to float32 (state-tensor dtype, :480) and the energy of the FULL
  * circuit at those angles is returned in f (the extra get_energy() of :291).  x receives
- * all n_params angles (the new rotation keeps its theta0 value), nfev COBYLA's count. */
+ * all n_params angles (the new rotation keeps its theta0 value), nfev COBYLA's count.
+ * A noise gate that directly follows gate new_gate[b] and acts on the same qubit(s) is the
+ * channel construct_ansatz attached to it (VQE_qulacs_TN_notin_RL_noise.py:26-28,40-50) and is
+ * left out of the optimised circuit with it; the noise draws of the COBYLA phase are numbered by
+ * gate position in that pre-action circuit, those of the final evaluation by position in the
+ * full one. */
 int vqe_batch_set_new_gate(vqe_t* h, const int32_t* new_gate /* batch, or NULL */);
 int vqe_batch_run_env_step(vqe_t* h, double rhobeg, double rhoend, int maxfun);
 int vqe_batch_fetch(vqe_t* h, double* x /* sum of n_params, may be NULL */,

@@ -29,6 +29,8 @@ def lib():
         L.orc_noise_gauss.argtypes = [C.c_uint64] * 3
         L.orc_noise_gauss.restype = C.c_double
         L.orc_noise_draws.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, i32p, C.c_double, C.c_double, i32p]
+        L.orc_noisy_energies.argtypes = [C.c_int, f64p, C.c_int, i32p, i32p, i32p, i32p, f64p, C.c_int, u64p, u64p, f64p,
+                                         C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_double, C.c_double, f64p]
         _lib = L
     return _lib
 
@@ -66,6 +68,21 @@ def noise_draws(seed, stream, eval_id, kind, p1, p2):
     kind = np.ascontiguousarray(kind, np.int32)
     out = np.zeros(kind.size, np.int32)
     lib().orc_noise_draws(seed, stream, eval_id, kind.size, _p(kind, i32p), p1, p2, _p(out, i32p))
+    return out
+
+
+def noisy_energies(n, psi0, kind, q0, q1, pidx, theta, xmask, zmask, coeff, seed, stream0, n_traj, eval_id, p1, p2):
+    """Energies of ``n_traj`` stochastic trajectories (streams stream0 .. stream0 + n_traj - 1) of one
+    circuit, each with the draws of (seed, stream, eval_id)."""
+    psi0 = np.ascontiguousarray(psi0, np.complex128)
+    kind, q0, q1, pidx = (np.ascontiguousarray(a, np.int32) for a in (kind, q0, q1, pidx))
+    theta = np.ascontiguousarray(theta, np.float64)
+    x, z = np.ascontiguousarray(xmask, np.uint64), np.ascontiguousarray(zmask, np.uint64)
+    c = np.ascontiguousarray(coeff, np.float64)
+    out = np.empty(n_traj, np.float64)
+    lib().orc_noisy_energies(n, psi0.view(np.float64).ctypes.data_as(f64p), kind.size, _p(kind, i32p), _p(q0, i32p),
+                             _p(q1, i32p), _p(pidx, i32p), _p(theta, f64p), c.size, _p(x, u64p), _p(z, u64p),
+                             _p(c, f64p), seed, stream0, n_traj, eval_id, p1, p2, _p(out, f64p))
     return out
 
 

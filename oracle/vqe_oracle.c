@@ -145,3 +145,27 @@ void orc_noise_draws(uint64_t seed, uint64_t stream, uint64_t eval, int n_gates,
     }
   }
 }
+
+/* n_traj stochastic evaluations of one circuit: trajectory t uses the draws of
+ * (seed, stream0 + t, eval) and returns sum_k w_k <psi_t|P_k|psi_t>.  Plain loop over the
+ * functions above (OpenMP over trajectories when built with -fopenmp): the checker for the
+ * distributional test of the noisy 12-qubit configuration. */
+void orc_noisy_energies(int n, const double* psi0, int n_gates, const int32_t* kind, const int32_t* q0,
+                        const int32_t* q1, const int32_t* pidx, const double* theta, int n_terms,
+                        const uint64_t* xmask, const uint64_t* zmask, const double* coeff, uint64_t seed,
+                        uint64_t stream0, int n_traj, uint64_t eval, double p1, double p2, double* out) {
+  const size_t dim = (size_t)1 << n;
+#pragma omp parallel
+  {
+    double* psi = (double*)malloc(dim * 2 * sizeof(double));
+    int32_t* draw = (int32_t*)malloc((size_t)(n_gates > 0 ? n_gates : 1) * sizeof(int32_t));
+#pragma omp for schedule(static)
+    for (int t = 0; t < n_traj; ++t) {
+      orc_noise_draws(seed, stream0 + (uint64_t)t, eval, n_gates, kind, p1, p2, draw);
+      orc_run_circuit(n, psi0, n_gates, kind, q0, q1, pidx, theta, draw, psi);
+      out[t] = orc_energy_pauli(n, psi, n_terms, xmask, zmask, coeff);
+    }
+    free(psi);
+    free(draw);
+  }
+}

@@ -20,6 +20,7 @@ SIGNATURES = {
     "vqe_destroy": (None, [vp]),
     "vqe_last_error": (C.c_char_p, [vp]),
     "vqe_set_stream": (C.c_int, [vp, vp]),
+    "vqe_get_stream": (C.c_int, [vp, C.POINTER(vp)]),
     "vqe_sync": (C.c_int, [vp]),
     "vqe_device_info": (C.c_int, [vp, c_i64p]),
     "vqe_set_init_state": (C.c_int, [vp, c_f64p]),

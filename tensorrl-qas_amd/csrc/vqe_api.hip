@@ -381,6 +381,9 @@ int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
 #endif
   if (lds > (size_t)h->lds_per_cu)
     return fail(h, VQE_EINVAL, "circuit too large for the LDS-resident path (gates + parameters)");
+  // register path: the raw ops are staged in the (idle) state region, 2^n records at most
+  if (N >= kRegMinQubits && (size_t)A.max_ops > ((size_t)1 << N))
+    return fail(h, VQE_EINVAL, "circuit too large for the LDS-resident path (more than 2^n rotations)");
   const void* fn = which == 0 ? (const void*)k_lds_energy<N>
                    : which == 1 ? (const void*)k_lds_minimize<N>
                                 : (const void*)k_lds_state<N>;
@@ -646,6 +649,12 @@ int vqe_set_stream(vqe_t* h, void* s) {
   if (!h) return VQE_EINVAL;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->stream = s ? (hipStream_t)s : h->own_stream;
+  return VQE_OK;
+}
+
+int vqe_get_stream(vqe_t* h, void** hip_stream) {
+  if (!h || !hip_stream) return VQE_EINVAL;
+  *hip_stream = (void*)h->stream;
   return VQE_OK;
 }
 

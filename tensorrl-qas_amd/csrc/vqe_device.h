@@ -356,7 +356,10 @@ struct Lds {
   uint16_t* sidx;   // [max_ops] position of raw op k in the executed list (sched for n >= 10, ops below)
 };
 
-// n >= 10: the raw ops only live while the schedule is built, in the (idle) state region.
+// n >= 10: the raw ops only live while the schedule is built, in the (idle) state region: in its
+// upper half next to the staged gate records when they fit there, else in all of it (launch_lds
+// refuses circuits with more than 2^n ops).
+__host__ __device__ inline bool ops_fit_upper_half(int n, int max_ops) { return (size_t)max_ops <= ((size_t)1 << n) / 2; }
 __host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params, int n_groups) {
   const int ng = n_groups > 0 ? n_groups : 1;
   size_t b = (size_t)16 << n;
@@ -370,7 +373,9 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, in
   Lds l;
   l.psi = (double2*)base; base += (size_t)16 << n;
   if (n >= 10) {
-    l.ops = (Op*)(l.psi) + (((size_t)1 << n) / 2);      // upper half of the state region
+    // raw ops: upper half of the state region (the lower half stages the gate records), or - for
+    // circuits with more than 2^(n-1) ops - the whole region (gates are then read from global memory)
+    l.ops = (Op*)(l.psi) + (ops_fit_upper_half(n, max_ops) ? ((size_t)1 << n) / 2 : 0);
     l.sched = (Op*)base; base += (size_t)16 * (2 * max_ops + 2);
     l.lay = (LayoutRec*)base; base += (size_t)32 * (max_ops + 2);
   } else {
@@ -422,11 +427,13 @@ __device__ __forceinline__ void stage_cls(const HamDev& H, const Lds& L) {
 // Pauli-Z slot per qubit it acts on (kind OP_NOP) and draws nothing; patch_noise() then sets,
 // for each evaluation, which slots are active and the sign bits that X errors flip - the
 // masks, the layouts and the schedule do not depend on the errors drawn.
+// Gates [skip, skip_end) are left out (the action just taken and the noise gate that belongs to it).
 __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t /*eval_id*/, const Lds& L, int skip = -1,
-                                            bool slots = false) {
+                                            bool slots = false, int skip_end = 0) {
   const int n = A.n;
   const int G = A.gate_count[b];
-  const int cap = (int)(((size_t)16 << n) / sizeof(GateRec)) / (n >= 10 ? 2 : 1);
+  const int cap = n >= 10 ? (ops_fit_upper_half(n, A.max_ops) ? (int)(((size_t)1 << n) / 2) : 0)
+                          : (int)(((size_t)16 << n) / sizeof(GateRec));
   const GateRec* gsrc = A.gates + A.gate_begin[b];
   GateRec* gl = (GateRec*)L.psi;
   const bool staged = G <= cap;
@@ -448,7 +455,7 @@ __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t 
       ++nops;
     };
     for (int i = 0; i < G; ++i) {
-      if (i == skip) continue;
+      if (i >= skip && i < skip_end) continue;
       const GateRec r = g[i];
       if (slots && (r.kind == G_DEPOL1 || r.kind == G_DEPOL2)) {
         slot(r.q0);
@@ -486,9 +493,13 @@ __device__ __forceinline__ void compile_ops(const BatchArgs& A, int b, uint64_t 
 // this (stream, evaluation) in parallel, then one thread walks the gate list tracking only the
 // offset c and patches the executed records in place: sign bit of every rotation, activity and
 // sign bit of every Pauli-Z slot.  `canonical`: the final scatter wants M c (see compile_all).
+// Gates [skip, skip_end) are not part of the circuit (as in compile_ops); the draw of a noise gate
+// is numbered by its position in the circuit that is actually executed, so a stochastic COBYLA
+// phase is exactly a run on the pre-action gate list (reference scipy_optim builds its circuit
+// from the pre-action state: environment_qulacs_TN_notin_agent_noise.py:372-380).
 template <int N>
 __device__ __forceinline__ void patch_noise_wave(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip,
-                                                 bool canonical, int lane) {
+                                                 bool canonical, int lane, int skip_end) {
   // One wave.  Lane l holds gate base+l and draws its Pauli error; everything that does not depend
   // on the running offset c (record numbers by a wave prefix sum, Z activity, the masks each gate
   // XORs into c) is prepared per lane, so the serial walk is a short branch-free scalar loop that
@@ -505,11 +516,11 @@ __device__ __forceinline__ void patch_noise_wave(const BatchArgs& A, int b, uint
     for (int base = 0; base < G; base += 64) {
       const int i = base + lane;
       int kind = -1, q0 = 0, q1 = 0, code = 0;
-      if (i < G && i != skip) {
+      if (i < G && !(i >= skip && i < skip_end)) {
         const int4 r = gsrc[i];
         kind = r.x; q0 = r.y; q1 = r.z < 0 ? 0 : r.z;
         if (kind == G_DEPOL1 || kind == G_DEPOL2) {
-          const double u = noise_uniform_k(nkey, (uint64_t)i);
+          const double u = noise_uniform_k(nkey, (uint64_t)(i - ((skip >= 0 && i >= skip_end) ? skip_end - skip : 0)));
           if (kind == G_DEPOL1) { if (u < A.noise.p1) code = 1 + (int)(u / A.noise.p1 * 3.0); }
           else if (u < A.noise.p2) code = 1 + (int)(u / A.noise.p2 * 15.0);
         }
@@ -567,8 +578,8 @@ __device__ __forceinline__ void patch_noise_wave(const BatchArgs& A, int b, uint
 // ... by wave 0 of the workgroup, followed by a barrier.
 template <int N>
 __device__ __forceinline__ void patch_noise(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip,
-                                            bool canonical) {
-  if (threadIdx.x < 64) patch_noise_wave<N>(A, b, eval_id, L, skip, canonical, (int)threadIdx.x);
+                                            bool canonical, int skip_end = 0) {
+  if (threadIdx.x < 64) patch_noise_wave<N>(A, b, eval_id, L, skip, canonical, (int)threadIdx.x, skip_end);
   __syncthreads();
 }
 
@@ -579,8 +590,8 @@ namespace vqe {
 // compile + (n >= 10) schedule for the register-resident path; ends with a barrier
 template <int N>
 __device__ __forceinline__ void compile_all(const BatchArgs& A, int b, uint64_t eval_id, const Lds& L, int skip = -1,
-                                            bool canonical = true, bool slots = false) {
-  compile_ops(A, b, eval_id, L, skip, slots);
+                                            bool canonical = true, bool slots = false, int skip_end = 0) {
+  compile_ops(A, b, eval_id, L, skip, slots, skip_end);
   if constexpr (N < 10) {   // (kRegMinQubits)
     if (slots) {
       for (int k = threadIdx.x; k < L.meta[0]; k += (int)blockDim.x) L.sidx[k] = (uint16_t)k;
@@ -1348,9 +1359,18 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
   const bool noisy = (A.noise.p1 > 0.0 || A.noise.p2 > 0.0);
   const int skip = A.new_gate ? A.new_gate[b] : -1;
   int p_hole = -1;
+  int skip_end = skip + 1;   // (no new gate: the empty range [-1, 0))
   if (skip >= 0) {
     const GateRec r = A.gates[A.gate_begin[b] + skip];
     if (r.kind >= G_RX && r.kind <= G_RZ) p_hole = r.pidx;
+    // the noise channel construct_ansatz puts behind every gate belongs to that gate: the
+    // pre-action circuit contains neither (VQE_qulacs_TN_notin_RL_noise.py:26-28,40-50)
+    if (skip + 1 < A.gate_count[b]) {
+      const GateRec f = A.gates[A.gate_begin[b] + skip + 1];
+      if ((f.kind == G_DEPOL1 && r.kind >= G_RX && r.kind <= G_RZ && f.q0 == r.q0) ||
+          (f.kind == G_DEPOL2 && r.kind == G_CNOT && f.q0 == r.q0 && f.q1 == r.q1))
+        skip_end = skip + 2;
+    }
   }
   const int Popt = P - (p_hole >= 0);
   stage_groups(A.ham, L);
@@ -1373,11 +1393,12 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
   for (;;) {
     const double* th = phase == 0 ? theta : (phase == 1 ? sc.x() : xout);
     const int sk = phase == 2 ? -1 : skip;
+    const int ske = phase == 2 ? 0 : skip_end;
     const int ph = phase == 2 ? -1 : p_hole;
     const uint64_t eid = A.noise.eval_base +
                          (phase == 1 ? (uint64_t)sc.nfvals : (phase == 2 ? (uint64_t)A.maxfun + 1 : 0));
-    if (need_compile) { compile_all<N>(A, b, 0, L, sk, true, noisy); need_compile = false; patched = false; }
-    if (noisy && !patched) patch_noise<N>(A, b, eid, L, sk, true);
+    if (need_compile) { compile_all<N>(A, b, 0, L, sk, true, noisy, ske); need_compile = false; patched = false; }
+    if (noisy && !patched) patch_noise<N>(A, b, eid, L, sk, true, ske);
     patched = false;
     double e = lds_evaluate<N>(A, L, th, P, ph);
     // finite-shot estimate of <H>: Gaussian with the total standard deviation the caller set
@@ -1398,7 +1419,7 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
       // while wave 0 updates the simplex, wave 1 draws and applies the errors of the next evaluation
       const uint64_t eid_next = A.noise.eval_base + (uint64_t)sc.nfvals + 1;
       const int want = sc.tell(e, A.dbg, [&]() {
-        if (noisy) patch_noise_wave<N>(A, b, eid_next, L, sk, true, (int)(threadIdx.x & 63));
+        if (noisy) patch_noise_wave<N>(A, b, eid_next, L, sk, true, (int)(threadIdx.x & 63), ske);
       });
       patched = noisy && want;
 #ifdef VQE_STAMPS

@@ -85,6 +85,12 @@ class VQEEngine:
     def set_stream(self, stream_ptr: int | None):
         self._chk(self._lib.vqe_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
 
+    def get_stream(self) -> int:
+        """The HIP stream the handle issues its work on (as an integer pointer)."""
+        p = C.c_void_p()
+        self._chk(self._lib.vqe_get_stream(self._h, C.byref(p)))
+        return int(p.value or 0)
+
     def sync(self):
         self._chk(self._lib.vqe_sync(self._h))
 
@@ -145,12 +151,16 @@ class VQEEngine:
 
     def get_state(self, theta) -> np.ndarray:
         th = _f64(theta)
+        if th.size != self._P:
+            raise ValueError("theta has the wrong length")
         out = np.empty(2 << self.n_qubits, np.float64)
         self._chk(self._lib.vqe_get_state(self._h, _p(th, c_f64p), _p(out, c_f64p)))
         return out.view(np.complex128)
 
     def minimize_cobyla(self, x0, rhobeg=1.0, rhoend=1e-4, maxfun=1000):
         x0 = _f64(x0)
+        if x0.size != self._P:
+            raise ValueError("x0 has the wrong length")
         x = np.empty_like(x0)
         f = C.c_double()
         nfev = C.c_int32()

@@ -48,7 +48,12 @@ def allreduce_sum(values, group=None):
     import torch.distributed as dist
     t = values if isinstance(values, torch.Tensor) else torch.as_tensor(np.asarray(values, np.float64))
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if not t.is_cuda and dist.get_backend(group) == "nccl":      # host values under RCCL: via this rank's GPU
+            d = t.to(torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(d)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -84,12 +89,30 @@ class TermShardedEngine:
             engine.set_term_shard(rank, world)
         self._buf = None
 
+    def _streams(self):
+        """(torch's current stream, the engine's stream wrapped for torch) or None when both are
+        the same stream.  The engine launches on its own HIP stream unless ``set_stream`` handed it
+        torch's; the all-reduce runs on torch's stream, so the two have to be ordered explicitly."""
+        import torch
+        cur = torch.cuda.current_stream(self.device)
+        ptr = self.engine.get_stream()
+        if ptr == cur.cuda_stream:
+            return None
+        return cur, torch.cuda.ExternalStream(ptr, device=self.device)
+
     def energies(self, batch: int):
         import torch
+        st = self._streams()
         if self._buf is None or self._buf.numel() != batch:
             self._buf = torch.zeros(batch, dtype=torch.float64, device=self.device)
+            if st is not None:
+                st[1].wait_stream(st[0])      # the fill lands before the engine's copy
+        elif st is not None:
+            st[1].wait_stream(st[0])          # the previous all-reduce has read the buffer
         self.engine.batch_run_energy()
         self.engine.batch_copy_energy(self._buf.data_ptr())
+        if st is not None:
+            st[0].wait_stream(st[1])          # the all-reduce starts after the copy
         return allreduce_sum(self._buf)
 
     def partial_energies(self):
@@ -124,13 +147,15 @@ def fit_restarts_sharded(fit_shard, n_restarts_total: int, group=None):
     val, gates = fit_shard(ids) if len(ids) else (float("inf"), None)
     if world == 1:
         return float(val), gates, 0
-    vals = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-    dist.all_gather(vals, torch.tensor([float(val)], dtype=torch.float64), group=group)
+    # RCCL moves device memory only: the few bytes exchanged live on this rank's GPU under "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    vals = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(vals, torch.tensor([float(val)], dtype=torch.float64, device=dev), group=group)
     owner = int(np.argmin([float(v[0]) for v in vals]))
-    shape = torch.tensor(list(np.shape(gates)) if rank == owner else [0, 0, 0], dtype=torch.int64)
+    shape = torch.tensor(list(np.shape(gates)) if rank == owner else [0, 0, 0], dtype=torch.int64, device=dev)
     dist.broadcast(shape, src=owner, group=group)
-    buf = torch.zeros(tuple(int(s) for s in shape) + (2,), dtype=torch.float64)
+    buf = torch.zeros(tuple(int(s) for s in shape.tolist()) + (2,), dtype=torch.float64, device=dev)
     if rank == owner:
         buf.copy_(torch.view_as_real(torch.as_tensor(np.ascontiguousarray(gates, np.complex128))))
     dist.broadcast(buf, src=owner, group=group)
-    return float(vals[owner][0]), torch.view_as_complex(buf).numpy().copy(), owner
+    return float(vals[owner][0]), torch.view_as_complex(buf.cpu()).numpy().copy(), owner

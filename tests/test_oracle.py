@@ -86,6 +86,15 @@ def test_noise_draws_and_pauli_application():
     assert len(seen) > 8
     u = [co.lib().orc_noise_uniform(7, 3, e, 1) for e in range(2000)]
     assert 0.45 < np.mean(u) < 0.55 and min(u) >= 0 and max(u) < 1
+    # the batched trajectory helper is the plain loop over the functions above
+    xs = np.array([0b0011, 0b0000, 0b0110], np.uint64)
+    zs = np.array([0b0001, 0b1010, 0b0110], np.uint64)
+    cs = np.array([0.7, -1.3, 0.4])
+    got = co.noisy_energies(n, psi0, kind, q0, q1, pidx, th, xs, zs, cs, 1234, 5, 40, 3, 0.3, 0.5)
+    for t in range(40):
+        dr = co.noise_draws(1234, 5 + t, 3, kind, 0.3, 0.5)
+        ref = vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th, dr), xs, zs, cs)
+        assert abs(got[t] - ref) < 1e-13
 
 
 def test_qasm_reader_and_layers():
