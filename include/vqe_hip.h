@@ -155,6 +155,15 @@ int vqe_batch_energy_devptr(vqe_t* h, void** dev_ptr);
 /* asynchronous device-to-device copy of that array into caller-owned device memory
  * (e.g. a torch tensor) on the handle's stream */
 int vqe_batch_copy_energy(vqe_t* h, void* dst_dev /* float64[batch] */);
+/* Diagnostic: record (f, x[0..P)) of every COBYLA evaluation of the next vqe_batch_run_minimize /
+ * vqe_batch_run_env_step launches (LDS-resident path), for trajectory-level comparison with
+ * scipy's callback sequence (environment_qulacs_TN_notin_agent.py:464-468,478).
+ * vqe_batch_fetch_trace copies circuit b's records: out[k * stride] = f of evaluation k + 1,
+ * out[k * stride + 1 + j] = its trial point (the optimised parameters only: the new gate's angle is
+ * not among them), zero beyond nfev; out == NULL only queries maxfun / stride. */
+int vqe_batch_set_trace(vqe_t* h, int enable);
+int vqe_batch_fetch_trace(vqe_t* h, int circuit, double* out /* maxfun * stride, or NULL */,
+                          int32_t* maxfun, int32_t* stride);
 /* diagnostic builds only (-DVQE_STAMPS): [0] evaluations, [1] cycles in the circuit phase,
  * [2] in the energy phase, [3] in the optimiser update, summed over workgroups; read and
  * cleared.  All zero in the shipped library (no stamp executes there). */

@@ -45,6 +45,8 @@ SIGNATURES = {
     "vqe_batch_fetch_xopt": (C.c_int, [vp, c_f64p]),
     "vqe_batch_energy_devptr": (C.c_int, [vp, C.POINTER(vp)]),
     "vqe_batch_copy_energy": (C.c_int, [vp, vp]),
+    "vqe_batch_set_trace": (C.c_int, [vp, C.c_int]),
+    "vqe_batch_fetch_trace": (C.c_int, [vp, C.c_int, c_f64p, c_i32p, c_i32p]),
     "vqe_debug_counters": (C.c_int, [vp, c_u64p]),
     "vqe_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "vqe_cobyla_create": (C.c_int, [C.c_int, c_f64p, C.c_double, C.c_double, C.c_int, C.POINTER(vp)]),

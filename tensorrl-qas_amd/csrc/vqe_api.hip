@@ -80,6 +80,9 @@ struct vqe_handle {
   DevBuf<double> d_theta, d_x, d_xraw, d_f, d_scratch;
   DevBuf<double2> d_state;
   DevBuf<unsigned long long> d_dbg;
+  DevBuf<double> d_trace;
+  bool trace_on = false;
+  int trace_maxfun = 0, trace_stride = 0, trace_batch = 0;
   StreamWork sw;  // streaming-path work buffers
 };
 
@@ -434,6 +437,7 @@ BatchArgs make_args(vqe_t* h) {
   A.max_params = h->max_params;
   A.state_out = h->d_state.p;
   A.dbg = h->d_dbg.p;
+  A.trace = nullptr;
   A.amp_rank = h->amp_rank;
   A.amp_world = h->amp_world;
   return A;
@@ -586,6 +590,13 @@ int run(vqe_t* h, int which, double rhobeg, double rhoend, int maxfun) {
                                "vqe_cobyla_ask/tell and sum the partial energies of all ranks");
   if (which == 4 && h->lds_path)
     return fail(h, VQE_ESTATE, "the reduction-only launch exists on the streaming path (n >= 14) only");
+  if (h->trace_on && which == 1 && h->lds_path) {
+    const size_t stride = (size_t)1 + (size_t)h->max_params, words = (size_t)h->batch * (size_t)maxfun * stride;
+    HIP_TRY(h, h->d_trace.reserve(words));
+    HIP_TRY(h, hipMemsetAsync(h->d_trace.p, 0, words * sizeof(double), h->stream));
+    A.trace = h->d_trace.p;
+    h->trace_maxfun = maxfun; h->trace_stride = (int)stride; h->trace_batch = h->batch;
+  }
   if (h->lds_path) rc = dispatch_lds(h, which, A);
   else rc = stream_run(h, which, A);
   if (rc) return rc;
@@ -908,6 +919,27 @@ int vqe_batch_copy_energy(vqe_t* h, void* dst_dev) {
   if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
   HIP_TRY(h, hipSetDevice(h->dev));
   HIP_TRY(h, hipMemcpyAsync(dst_dev, h->d_f.p, (size_t)h->batch * 8, hipMemcpyDeviceToDevice, h->stream));
+  return VQE_OK;
+}
+
+int vqe_batch_set_trace(vqe_t* h, int enable) {
+  if (!h) return VQE_EINVAL;
+  if (enable && !h->lds_path) return fail(h, VQE_ESTATE, "evaluation traces are recorded by the fused device loop (n <= 13) only");
+  h->trace_on = enable != 0;
+  return VQE_OK;
+}
+
+int vqe_batch_fetch_trace(vqe_t* h, int circuit, double* out, int32_t* maxfun, int32_t* stride) {
+  if (!h || !maxfun || !stride) return VQE_EINVAL;
+  if (h->trace_maxfun <= 0) return fail(h, VQE_ESTATE, "no trace recorded: vqe_batch_set_trace(1), then a minimize / env-step run");
+  if (circuit < 0 || circuit >= h->trace_batch) return fail(h, VQE_EINVAL, "circuit index out of range");
+  *maxfun = h->trace_maxfun;
+  *stride = h->trace_stride;
+  if (!out) return VQE_OK;      // size query
+  HIP_TRY(h, hipSetDevice(h->dev));
+  const size_t words = (size_t)h->trace_maxfun * (size_t)h->trace_stride;
+  HIP_TRY(h, hipMemcpyAsync(out, h->d_trace.p + (size_t)circuit * words, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   return VQE_OK;
 }
 

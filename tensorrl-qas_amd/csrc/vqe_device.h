@@ -127,6 +127,7 @@ struct BatchArgs {
   int maxfun;
   double2* state_out;          // get_state: [2^n]
   unsigned long long* dbg;     // [8] phase cycle counters, written only by -DVQE_STAMPS builds
+  double* trace;               // NULL, or [batch][maxfun][1 + max_params]: (f, x[]) of every COBYLA evaluation (vqe_batch_set_trace)
   int amp_rank, amp_world;     // streaming path: this handle sweeps slice amp_rank of amp_world of the amplitudes
 };
 
@@ -1413,6 +1414,11 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
       finished_opt = true;
     } else if (phase == 1) {
       flast = e;
+      if (A.trace) {   // diagnostic: the trial point and its value, for trajectory-level parity tests
+        double* tr = A.trace + ((size_t)b * A.maxfun + (size_t)(sc.nfvals - 1)) * (size_t)(1 + A.max_params);
+        if (threadIdx.x == 0) tr[0] = e;
+        for (int j = threadIdx.x; j < Popt; j += kThreads) tr[1 + j] = sc.x()[j];
+      }
 #ifdef VQE_STAMPS
       const long long tt0 = clock64();
 #endif

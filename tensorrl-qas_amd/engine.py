@@ -235,6 +235,18 @@ class VQEEngine:
     def batch_copy_energy(self, dst_dev_ptr: int):
         self._chk(self._lib.vqe_batch_copy_energy(self._h, C.c_void_p(int(dst_dev_ptr))))
 
+    def batch_set_trace(self, enable: bool = True):
+        self._chk(self._lib.vqe_batch_set_trace(self._h, int(bool(enable))))
+
+    def batch_fetch_trace(self, circuit: int, n_params: int):
+        """(f[k], x[k, :n_params]) of every evaluation the device COBYLA loop made for ``circuit``
+        in the last traced run (rows beyond its nfev are zero)."""
+        mf, st = C.c_int32(), C.c_int32()
+        self._chk(self._lib.vqe_batch_fetch_trace(self._h, int(circuit), C.cast(None, c_f64p), C.byref(mf), C.byref(st)))
+        out = np.zeros((mf.value, st.value), np.float64)
+        self._chk(self._lib.vqe_batch_fetch_trace(self._h, int(circuit), _p(out, c_f64p), C.byref(mf), C.byref(st)))
+        return out[:, 0].copy(), out[:, 1:1 + n_params].copy()
+
     def debug_counters(self):
         out = np.zeros(8, np.uint64)
         self._chk(self._lib.vqe_debug_counters(self._h, _p(out, c_u64p)))
