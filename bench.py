@@ -17,6 +17,11 @@ HBM before the timed region and are not modified by a step, so every step does i
 work.  Multi-GPU: environments are sharded over ranks (replicas, no data-path collective,
 weak scaling); the auxiliary ``heis20`` object times the 20-qubit Heisenberg <H> with Pauli
 terms sharded over the ranks and ONE RCCL all-reduce of the partial energies.
+
+Launch: under torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) every process is one rank.
+Started plainly with --gpus N > 1 and no WORLD_SIZE, this process spawns the N ranks itself
+(`python -m torch.distributed.run ...` as a child, before anything here touches the GPU) and exits
+with the child's code; the JSON line carries `ranks_seen` = torch.distributed's world size.
 """
 import argparse
 import json
@@ -58,14 +63,38 @@ def make_batch(tq, n, B, G, seed):
                 par_off=par_off, theta=theta, new_gate=new_gate, pcount=pcount)
 
 
-def cpu_baseline(tq, ham, psi0, batch, G, n_steps, maxfun):
+def _cpu_facts():
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    blas = ""
+    try:
+        from threadpoolctl import threadpool_info
+        blas = "; ".join(f"{p.get('internal_api')} {p.get('version')} ({p.get('num_threads')} threads)"
+                         for p in threadpool_info() if p.get("user_api") == "blas")
+    except Exception:
+        pass
+    return model, blas
+
+
+def cpu_baseline(tq, ham, psi0, batch, G, n_steps, maxfun, one_thread_evals=400):
     """Reference algorithm on the host cores for a bounded sample of the same workload:
     C restatement of the qulacs gate sweeps (oracle/vqe_oracle.c) + the literal dense
-    numpy expression (VQE_qulacs_TN_notin_RL.py:86) inside scipy's COBYLA (:478)."""
+    numpy expression (VQE_qulacs_TN_notin_RL.py:86) inside scipy's COBYLA (:478).
+    Timed twice: with the BLAS pool at all host cores (`value`: whole env-steps) and at ONE thread
+    (the reference pins torch to one thread, TensorRL_fixed_noiseless.py:13; qulacs' small-n kernels are
+    single-threaded): there a bounded number of evaluations of the same COBYLA run, converted with the
+    workload's evaluations per env-step."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle as co
     import vqe_oracle as vo
     from scipy.optimize import minimize
+    from threadpoolctl import threadpool_limits
     n = N_QUBITS
     idx = np.arange(2 ** n)
     dense = np.zeros((2 ** n, 2 ** n), np.complex128)
@@ -73,14 +102,15 @@ def cpu_baseline(tq, ham, psi0, batch, G, n_steps, maxfun):
         x, z = int(x), int(z)
         ny = bin(x & z).count("1")
         dense[idx ^ x, idx] += w * (1.0 - 2.0 * vo._parity(idx & z)) * (1j ** ny)
+    nproc = os.cpu_count() or 1
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    evals = 0
-    t0 = time.perf_counter()
-    for b in range(n_steps):
+        nproc = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    model, blas = _cpu_facts()
+
+    def env_step(b, budget=None):
+        """One CircuitEnv.step() of circuit b on the CPU; `budget`: stop after that many evaluations."""
         g0, g1 = batch["gate_off"][b], batch["gate_off"][b + 1]
         p0, p1 = batch["par_off"][b], batch["par_off"][b + 1]
         kind, q0, q1, pidx = (batch[k][g0:g1] for k in ("kind", "q0", "q1", "pidx"))
@@ -88,22 +118,47 @@ def cpu_baseline(tq, ham, psi0, batch, G, n_steps, maxfun):
         pre = slice(0, G - 1)
         hole = int(pidx[-1])
         x0 = th if hole < 0 else th[:hole]          # the new rotation is the last parameter
+        count = [0]
+
+        class Budget(Exception):
+            pass
 
         def cost(x, k=kind[pre], a=q0[pre], bq=q1[pre], p=pidx[pre]):
+            if budget is not None and count[0] >= budget:
+                raise Budget
+            count[0] += 1
             psi = co.run_circuit(n, psi0, k, a, bq, p, x)
             return float((np.conj(psi).T @ dense @ psi).real)
 
-        r = minimize(cost, x0, method="COBYLA", options={"maxiter": maxfun})
+        try:
+            r = minimize(cost, x0, method="COBYLA", options={"maxiter": maxfun})
+        except Budget:
+            return count[0]
         full = th.copy()
         full[:x0.size] = r.x.astype(np.float32)
         psi = co.run_circuit(n, psi0, kind, q0, q1, pidx, full)
         _ = float((np.conj(psi).T @ dense @ psi).real)
-        evals += r.nfev + 1
+        return r.nfev + 1
+
+    evals = 0
+    t0 = time.perf_counter()
+    with threadpool_limits(limits=nproc, user_api="blas"):
+        for b in range(n_steps):
+            evals += env_step(b)
     dt = time.perf_counter() - t0
-    return {"value": n_steps / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n_steps} env-steps of the same batch ({evals} evaluations, {dt:.1f} s): C gate sweeps "
-                      f"+ numpy dense (conj(psi)@H)@psi + scipy {__import__('scipy').__version__} COBYLA",
-            "evals_per_s": evals / dt}
+    per_step = evals / n_steps
+    with threadpool_limits(limits=1, user_api="blas"):
+        t1 = time.perf_counter()
+        e1 = env_step(0, budget=one_thread_evals)
+        d1 = time.perf_counter() - t1
+    return {"value": n_steps / dt, "unit": "env-steps/s", "cores": int(nproc), "kind": "port",
+            "sample": f"{n_steps} env-steps of the same batch ({evals} evaluations, {dt:.1f} s), BLAS pool at {nproc} threads: "
+                      f"C gate sweeps + numpy dense (conj(psi)@H)@psi + scipy {__import__('scipy').__version__} COBYLA",
+            "evals_per_s": evals / dt,
+            "one_thread": {"value": (e1 / d1) / per_step, "unit": "env-steps/s", "cores": 1, "evals_per_s": e1 / d1,
+                           "sample": f"first {e1} evaluations of env-step 0 ({d1:.1f} s) at 1 BLAS thread, converted with "
+                                     f"{per_step:.0f} evaluations per env-step of this workload"},
+            "nproc": int(nproc), "cpu_model": model, "blas": blas}
 
 
 def episode_aux(tq, torch, dev, num_envs, max_steps, barrier=None, seed0=0):

@@ -41,6 +41,9 @@
 #define CBY_STAMP(k)
 #define CBY_STAMP_RESET()
 #endif
+#ifndef CBY_LOG   // decision log, compiled in only by tests/cpp/cobyla_wave_emulation.cpp
+#define CBY_LOG(...)
+#endif
 
 namespace cby {
 
@@ -61,6 +64,7 @@ struct HostCtx {
   static constexpr int kPad = 1;   // inner loops run to exactly n
   static constexpr bool kSplit = false;   // no second lane to share a row with
   CBY_HD double pair_sum(double v) const { return v; }
+  CBY_HD void lockstep() const {}   // see the one call site
 
   CBY_HD void sync() const {}
   CBY_HD int all_or(int v) const { return v; }
@@ -328,11 +332,16 @@ struct CobylaM0 {
         double phimin;
         int nbest = ctx.arg_first(n, [&](int j) { return datmat[j]; }, datmat[nv], false, &phimin);
         if (nbest < 0) nbest = n;
+        CBY_LOG("140: nfvals %d nbest %d phimin %.17g rho %g ibrnch %d", nfvals, nbest, phimin, rho, ibrnch);
         ctx.sync();
         if (nbest < n) {
           if (ctx.tid == 0) { const double t = datmat[nv]; datmat[nv] = datmat[nbest]; datmat[nbest] = t; }
           for (int i = rlane; i < n; i += rstep) {
             const double temp = SIM(i, nbest);
+            // two lanes may share row i (kSplit): both must have read SIM(i, nbest) before its owner
+            // overwrites it below.  One wavefront executes in lock step, so this is a no-op on the
+            // GPU; an emulation with free-running threads synchronises the pair here.
+            if (split) ctx.lockstep();
             if (ilo == 0) SIM(i, nv) += temp;
             double tempa = 0.0;
             for (int k0 = ilo; k0 < ihi; k0 += P) {   // (dummy vertices n..nv-1: harmless)
@@ -395,6 +404,7 @@ struct CobylaM0 {
           if (vs < parsig || ve > pareta) flag_bad = 1;
         }
         iflag = ctx.all_or(flag_bad) ? 0 : 1;  // all_or synchronises
+        CBY_LOG("    acceptable %d (parsig %.17g pareta %.17g)", iflag, parsig, pareta);
         CBY_STAMP(5);
         if (ibrnch == 1 || iflag == 1) { lbl = 370; continue; }
         // ---- geometry step: replace the worst-placed vertex
@@ -402,10 +412,12 @@ struct CobylaM0 {
         int jd = ctx.arg_first(n, [&](int j) { return veta[j]; }, pareta, true, &temp);
         if (jd < 0) jd = ctx.arg_first(n, [&](int j) { return vsig[j]; }, pareta, false, &temp);
         jdrop = jd;
+        CBY_LOG("    geometry step: jdrop %d (veta/vsig extreme %.17g)", jd, temp);
         temp = 0.5 * rho * vsig[jdrop];
         const double sum = ctx.sum(n, [&](int i) { return a[i] * (temp * SIMI(jdrop, i)); });
         // dxsign = -1 iff parmu*(cvmaxp-cvmaxm) > 2*sum with parmu = 0
         const double dxsign = (0.0 > sum + sum) ? -1.0 : 1.0;
+        CBY_LOG("    geometry sum %.17g dxsign %g", sum, dxsign);
         ctx.sync();
         for (int i = ctx.tid; i < n; i += ctx.nth) {
           const double d = dxsign * (temp * SIMI(jdrop, i));
@@ -426,6 +438,7 @@ struct CobylaM0 {
         }
         // sum = 0 - a.dx accumulated term by term; prerem = parmu*prerec - sum with parmu = 0
         prerem = ctx.sum(n, [&](int i) { return a[i] * dx[i]; });
+        CBY_LOG("370: trust-region step, prerem %.17g ifull %d", prerem, ifull);
         ctx.sync();
         for (int i = ctx.tid; i < n; i += ctx.nth) x[i] = SIM(i, nv) + dx[i];
         ibrnch = 1;
@@ -480,6 +493,7 @@ struct CobylaM0 {
         ctx.sync();
         double edgmax;
         const int l = ctx.arg_first(n, [&](int j) { return w[j]; }, 1.1 * rho, true, &edgmax);
+        CBY_LOG("440: trured %.17g prerem %.17g jd(ratio) %d ratio %.17g l(edge) %d edgmax %.17g", trured, prerem, jd, ratio, l, edgmax);
         if (l >= 0) jd = l;
         if (jd < 0) { lbl = 550; continue; }
         jdrop = jd;
@@ -495,6 +509,7 @@ struct CobylaM0 {
         continue;
       }
       // lbl == 550
+      CBY_LOG("550: iflag %d rho %g", iflag, rho);
       if (iflag == 0) { ibrnch = 0; lbl = 140; continue; }
       if (rho > rhoend) {
         rho = 0.5 * rho;

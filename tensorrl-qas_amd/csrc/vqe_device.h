@@ -218,6 +218,7 @@ struct WaveCtx {
     const bool up = tid >= 32;
     return v + __hiloint2double(up ? r1[0] : r1[1], up ? r0[0] : r0[1]);
   }
+  __device__ __forceinline__ void lockstep() const {}   // a wavefront IS in lock step
   // LDS / global accesses of one wave execute in order; the fence keeps the compiler (and the
   // memory counters) from moving accesses across the point where lanes exchange data.
   __device__ __forceinline__ void sync() const {
@@ -274,6 +275,7 @@ struct BlockCtx {
   static constexpr int kPad = 8;
   static constexpr bool kSplit = false;
   __device__ __forceinline__ double pair_sum(double v) const { return v; }
+  __device__ __forceinline__ void lockstep() const {}   // kSplit = false: a row has one owner
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ __forceinline__ int all_or(int v) const {   // (HIP's __syncthreads_or allocates static LDS)
     const int any = __ballot(v != 0) != 0ull;

@@ -128,19 +128,28 @@ def test_noisy_env_step_optimises_pre_action_circuit(tq):
         sel = [j for j in range(P) if j != hole]
         pk, pa, pb = kind[keep], q0[keep], q1[keep]
         pp = np.where(pidx[keep] > hole, pidx[keep] - 1, pidx[keep]) if hole >= 0 else pidx[keep]
-        hx, hf = [], []
-        opt = tq.HostCobyla(th[sel], 1.0, 1e-4, maxfun)
-        while (t := opt.ask()) is not None:
-            dr = co.noise_draws(seed, b, len(hf) + 1, pk, p1, p2)      # evaluation ids 1, 2, ...
-            hx.append(t), hf.append(vo.energy_pauli(vo.run_circuit(psi0, pk, pa, pb, pp, t, dr), *ham))
-            opt.tell(hf[-1])
+        # every evaluation of the COBYLA phase: the device's value at the device's trial point is the
+        # oracle's energy of the PRE-action circuit there, with the draws of evaluation k + 1 numbered by
+        # gate position in that circuit
         ft, xt = eng.batch_fetch_trace(b, len(sel))
-        # identical trial points and noisy values through the initial simplex and the next steps; a
-        # cost that jumps by O(1) between evaluations soon degenerates the simplex, after which
-        # last-bit differences between the two COBYLA builds are amplified beyond any tolerance
-        need = min(int(nfev[b]), len(hf), len(sel) + 1 + 3)
-        for k in range(need):
-            assert np.abs(xt[k] - hx[k]).max() < 1e-8 and abs(ft[k] - hf[k]) < E_TOL, (b, k, xt[k], hx[k], ft[k], hf[k])
+        for k in range(int(nfev[b]) if sel else 0):
+            dr = co.noise_draws(seed, b, k + 1, pk, p1, p2)
+            e_ref = vo.energy_pauli(vo.run_circuit(psi0, pk, pa, pb, pp, xt[k], dr), *ham)
+            assert abs(ft[k] - e_ref) < E_TOL, (b, k, ft[k], e_ref)
+        # ... and the trial points are COBYLA's: the library's host build (bit-exact with scipy), told the
+        # device's values, proposes the same points through the initial simplex and beyond - until a
+        # comparison that is a tie in exact arithmetic is decided by the summation order
+        # (tests/test_cobyla_emulation.py)
+        opt = tq.HostCobyla(th[sel], 1.0, 1e-4, maxfun)
+        agree = 0
+        for k in range(int(nfev[b]) if sel else 0):
+            t = opt.ask()
+            if t is None or np.abs(t - xt[k]).max() > 1e-7:
+                break
+            opt.tell(ft[k])
+            agree += 1
+        assert agree >= min(int(nfev[b]), len(sel) + 2) or not sel, (b, agree, nfev[b])
+        print(f"noisy env-step {b}: P={len(sel)} nfev={nfev[b]}, every value checked; host replay in step for {agree} evaluations")
         assert 1 <= nfev[b] <= maxfun
         if hole >= 0:
             assert xb[hole] == th[hole] == 0.0

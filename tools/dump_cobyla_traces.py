@@ -1,0 +1,53 @@
+"""GPU: dump device COBYLA traces (x0, f history, trial points) for the CPU emulation harness
+(tests/cpp/cobyla_wave_emulation.cpp).  Output: gpurun_out/cobyla_traces/<case>.txt; the copies under
+tests/golden/cobyla_device_traces/ are the fixtures of tests/test_cobyla_emulation.py (recorded on an
+MI355X; regenerate them whenever the arithmetic of the device optimiser changes)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import tensorrl_qas_amd as tq
+from helpers import random_hamiltonian, random_state
+from test_configs_gpu import _tie_free_gates
+
+out = os.path.join(ROOT, "gpurun_out", "cobyla_traces")
+if __name__ == "__main__":
+    os.makedirs(out, exist_ok=True)
+def write_trace(path, th, ft, xt, nf):
+    with open(path, "w") as fh:
+        fh.write(f"{th.size} {nf}\n")
+        fh.write(" ".join(float(v).hex() for v in th) + "\n")
+        for k in range(nf):
+            fh.write(float(ft[k]).hex() + " " + " ".join(float(v).hex() for v in xt[k]) + "\n")
+
+
+# (n, P, seed, shot-noise sigma, maxfun): LDS-staged and global-scratch matrices, rows split over lane
+# pairs (2 P8 <= 64) and not, smooth and jumpy objective (the latter drives the geometry-step branches)
+CASES = ((12, 9, 3, 0.0, 200), (8, 10, 2, 0.5, 120), (5, 6, 1, 0.5, 80), (12, 9, 3, 0.5, 110), (10, 24, 6, 0.0, 110),
+         (8, 40, 8, 0.0, 90))
+
+
+def device_trace(n, P, seed, sigma, maxfun):
+    rng = np.random.default_rng(70 + seed)
+    psi0 = random_state(n, rng); ham = random_hamiltonian(n, 30, rng)
+    kind, q0, q1, pidx, th = _tie_free_gates(n, P, rng)
+    eng = tq.VQEEngine(n); eng.set_init_state(psi0); eng.set_hamiltonian(*ham)
+    if sigma:
+        eng.set_shot_noise(sigma, 99)
+    c = tq.Circuit(kind, q0, q1, pidx, P)
+    eng.batch_set_trace(True)
+    eng.batch_load([c], [th]); eng.batch_run_minimize(1.0, 1e-4, maxfun)
+    x, f, nfev = eng.batch_fetch()
+    ft, xt = eng.batch_fetch_trace(0, P)
+    return th, ft, xt, int(nfev[0])
+
+
+def case_name(n, P, seed, sigma, maxfun):
+    return f"n{n}_P{P}_s{seed}_{'shot' if sigma else 'clean'}.txt"
+
+
+if __name__ == "__main__":
+    for case in CASES:
+        th, ft, xt, nf = device_trace(*case)
+        write_trace(os.path.join(out, case_name(*case)), th, ft, xt, nf)
+        print(case, nf)
