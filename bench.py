@@ -343,6 +343,91 @@ def heis20_aux(tq, torch, dist, rank, world, dev, steps):
             "x_groups_total": 20, "sharding": "amplitude slices of the term sum, 1 all-reduce", "energy_checksum": float(e.sum().item()), "scaling": "strong"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process
+    (torchrun's elastic launcher), BEFORE anything here initialises the GPU - a process that has touched
+    the GPU must never be replaced or forked into ranks.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_selftest(args, rank, world):
+    """CPU rehearsal of the multi-rank launch path (tests/test_distributed_cpu.py): rendezvous, one
+    all-reduce, rank 0 prints the JSON line - no GPU work."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": args.gpus, "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                          "backend": args.backend if world > 1 else None, "rank_sum": float(t.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def pmc_roofline(workload, k_ms, evals_per_launch):
+    """Roofline of the LDS-resident kernel from rocprofv3 counters of THIS workload (profiles/pmc_lds_minimize.json,
+    written by tools/pmc.sh from separate --pmc passes): the executed FP64 vector flops, LDS-array cycles and HBM bytes
+    of one launch are properties of the workload (same seeds, same instruction stream); they are divided by the kernel
+    duration measured live in this run."""
+    path = os.path.join(ROOT, "profiles", "pmc_lds_minimize.json")
+    if not os.path.exists(path):
+        return None
+    pm = json.load(open(path))
+    if pm.get("workload") != workload:
+        return None
+    c = pm["per_launch"]
+    sec = k_ms * 1e-3
+    flop = (2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]) * 64.0
+    hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0        # gfx950: FETCH_SIZE counts half of wide reads
+    out = {"bound": "fp64_valu", "achieved": flop / sec / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": flop / sec / 1e12 / FP64_PEAK_TFLOPS, "traffic": hbm,
+           "flop_per_launch": flop, "flop_per_evaluation": flop / pm["evaluations_per_launch"],
+           "source": pm["source"],
+           "note": "executed FP64 vector flops (2 FMA + MUL + ADD wave instructions x 64 lanes) of one launch / kernel "
+                   "duration of this run; the state never leaves VGPRs / LDS, so neither HBM nor MFMA binds - the FP64 "
+                   "vector pipe peaks at the same 78.6 TFLOP/s as the FP64 matrix pipe on MI355X",
+           "hbm": {"achieved": hbm / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / sec / 1e9 / HBM_PEAK_GBS},
+           "fp64_share_of_wave_instructions": (c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"])
+           / max(1.0, c.get("SQ_INSTS_ALL", 0.0)) if c.get("SQ_INSTS_ALL") else None}
+    if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
+        # LDS-array cycles summed over the CUs / (CUs x kernel cycles): utilisation of the LDS pipes
+        cus = pm.get("cu_count", 256)
+        out["lds"] = {"array_cycles_per_launch": c["SQ_LDS_IDX_ACTIVE"], "bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"),
+                      "frac": c["SQ_LDS_IDX_ACTIVE"] / (cus * c["GRBM_GUI_ACTIVE"]),
+                      "note": "SQ_LDS_IDX_ACTIVE / (CUs x GRBM_GUI_ACTIVE): share of cycles the LDS arrays are busy"}
+    return out
+
+
+def g_sweep(tq, eng, n, B, maxfun, rank):
+    """RL-depth sweep G in {8, 32, 64, 110} of the same generator, one fused launch each."""
+    out = []
+    for G in (8, 32, 64, 110):
+        b = make_batch(tq, n, B, G, 1000 + rank)
+        eng.batch_load_flat(b["gate_off"], b["kind"], b["q0"], b["q1"], b["pidx"], b["par_off"], b["theta"])
+        eng.batch_set_new_gate(b["new_gate"])
+        eng.batch_run_env_step(1.0, 1e-4, maxfun)
+        eng.sync()
+        ms = eng.last_kernel_ms()
+        _, _, nfev = eng.batch_fetch(want_x=False)
+        out.append({"gates": G, "mean_params": float(np.mean(b["pcount"])), "env_steps_per_s_per_gpu": B / (ms * 1e-3),
+                    "evals_per_s_per_gpu": float(nfev.sum() + B) / (ms * 1e-3), "mean_nfev": float(nfev.mean()), "kernel_ms": ms})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,28 +440,44 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-heis20", action="store_true")
     ap.add_argument("--no-mps2qc", action="store_true")
-    ap.add_argument("--episode", action="store_true", help="also run the LIH12q fixed config through "
-                    "VecCircuitEnv (adds launches of the same kernel with other sizes: keep it out of profiled runs)")
-    ap.add_argument("--episode-envs", type=int, default=1024)
-    ap.add_argument("--episode-steps", type=int, default=110)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-sweep", action="store_true", help="skip the G in {8,32,64,110} auxiliary launches")
+    ap.add_argument("--no-episode", action="store_true", help="skip the LIH12q fixed config through VecCircuitEnv")
+    ap.add_argument("--episode", action="store_true", help="(default at N = 1; kept for older command lines)")
+    ap.add_argument("--episode-envs", type=int, default=2048)
+    ap.add_argument("--episode-steps", type=int, default=24)
+    ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' "
                     "only to rehearse the multi-rank code path on a box with fewer GPUs than ranks")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed launches of the headline kernel (profiling "
+                    "runs: no warm-start / sweep / episode / heis20 / mps2qc / cpu_baseline launches in the trace)")
+    ap.add_argument("--selftest-launch", action="store_true", help="CPU rehearsal of the multi-rank launch path (no GPU work)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_heis20 = args.no_mps2qc = args.no_sweep = args.no_episode = True
+
+    # ---- launch: under torchrun every process is a rank; started plainly with --gpus N > 1 this process
+    # spawns the ranks itself, before anything touches the GPU
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` or "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    if args.selftest_launch:
+        return launch_selftest(args, rank, world)
 
     import torch
     import torch.distributed as dist
     import tensorrl_qas_amd as tq
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the VQE engine has no CPU fallback")
     if args.backend != "nccl":                   # rehearsal: ranks share the visible GPUs
         local = local % torch.cuda.device_count()
+    elif world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPUs are visible")
     torch.cuda.set_device(local)
     torch.cuda.set_stream(torch.cuda.Stream())   # one explicit stream for the engine, copies and RCCL
     if world > 1:
@@ -385,6 +486,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    ranks_seen = dist.get_world_size() if world > 1 else 1
 
     n, B, G = N_QUBITS, args.envs, args.gates
     ham = tq.hamiltonian.synthetic_lih12()
@@ -426,7 +528,6 @@ def main():
     T, Tx = ham.n_terms, ham.n_xgroups
     bytes_per_eval = (2 ** n) * 16 * (2 * (G - 1) + T)          # 2^n*16*(2G+T)
     bytes_per_eval_grouped = (2 ** n) * 16 * (2 * (G - 1) + Tx)
-    achieved = evals_per_launch * bytes_per_eval / (k_ms * 1e-3) / 1e9
     stats = torch.tensor([float(nfev.sum()), float(B)], dtype=torch.float64, device=f"cuda:{local}")
     if world > 1:
         dist.all_reduce(stats)
@@ -434,19 +535,22 @@ def main():
 
     # auxiliary: the same batch warm-started from its own optimum (what an RL episode does:
     # x0 of a step is the previous step's optimum), one fused launch
-    x_opt, _, _ = eng.batch_fetch()
-    eng.batch_load_flat(batch["gate_off"], batch["kind"], batch["q0"], batch["q1"], batch["pidx"],
-                        batch["par_off"], x_opt)
-    eng.batch_set_new_gate(batch["new_gate"])
-    eng.batch_run_env_step(1.0, 1e-4, args.maxfun)
-    torch.cuda.synchronize()
-    warm_ms = eng.last_kernel_ms()
-    _, _, nfev_w = eng.batch_fetch(want_x=False)
-    warm = {"env_steps_per_s_per_gpu": B / (warm_ms * 1e-3), "mean_nfev": float(nfev_w.mean()),
-            "note": "same circuits, x0 = optimum of the previous step (float32), kernel time only"}
+    warm = None
+    if not args.headline_only:
+        x_opt, _, _ = eng.batch_fetch()
+        eng.batch_load_flat(batch["gate_off"], batch["kind"], batch["q0"], batch["q1"], batch["pidx"],
+                            batch["par_off"], x_opt)
+        eng.batch_set_new_gate(batch["new_gate"])
+        eng.batch_run_env_step(1.0, 1e-4, args.maxfun)
+        torch.cuda.synchronize()
+        warm_ms = eng.last_kernel_ms()
+        _, _, nfev_w = eng.batch_fetch(want_x=False)
+        warm = {"env_steps_per_s_per_gpu": B / (warm_ms * 1e-3), "mean_nfev": float(nfev_w.mean()),
+                "note": "same circuits, x0 = optimum of the previous step (float32), kernel time only"}
+    sweep = None if args.no_sweep else g_sweep(tq, eng, n, B, args.maxfun, rank)
 
     episode = None
-    if args.episode and rank == 0:
+    if not args.no_episode and rank == 0 and world == 1:
         episode = episode_aux(tq, torch, local, args.episode_envs, args.episode_steps)
     if world > 1:
         dist.barrier()
@@ -456,33 +560,37 @@ def main():
         heis = heis20_aux(tq, torch, dist, rank, world, local, max(2, args.steps))
 
     if rank == 0:
+        workload = f"lih12_synthetic631_fixed_noiseless_G{G}_B{B}_per_gpu"
+        roof = pmc_roofline(workload, k_ms, evals_per_launch)
+        if roof is None:      # no counter file for this workload: say so instead of inventing a fraction
+            roof = {"bound": "fp64_valu", "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                    "traffic": None, "note": "no profiles/pmc_lds_minimize.json for this workload (tools/pmc.sh)"}
+        roof.update({"kernel": "k_lds_minimize<12>", "kernel_ms": k_ms, "evaluations_per_launch": evals_per_launch,
+                     "algorithmic": {"bytes_per_evaluation": bytes_per_eval, "bytes_per_evaluation_xgrouped": bytes_per_eval_grouped,
+                                     "GBs_if_streamed_from_hbm": evals_per_launch * bytes_per_eval / (k_ms * 1e-3) / 1e9,
+                                     "note": "SURVEY 8d figure 2^n*16*(2G+T) x evaluations / kernel time: what a kernel that "
+                                             "streamed the state through HBM for every gate and term would have to move; "
+                                             "informational only - this kernel keeps the state in VGPRs / LDS"}})
         out = {
             "metric": "VQE env-steps/sec", "value": world * B * args.steps / dt, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"lih12_synthetic631_fixed_noiseless_G{G}_B{B}_per_gpu",
+            "config": {"workload": workload,
                        "n_qubits": n, "pauli_terms": T, "x_groups": Tx, "gates": G, "envs_per_gpu": B,
                        "cobyla": {"rhobeg": 1.0, "rhoend": 1e-4, "maxfun": args.maxfun},
                        "mean_nfev": mean_nfev, "parallelism": f"env-replicas x{world}"},
             "evals_per_s": world * evals_per_launch / (k_ms * 1e-3),
             "energy_checksum": float(np.sum(f)),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_lds_minimize<12>", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_eval": bytes_per_eval,
-                         "achieved_xgrouped": evals_per_launch * bytes_per_eval_grouped / (k_ms * 1e-3) / 1e9,
-                         "note": "state is LDS-resident: algorithmic bytes never reach HBM, frac may exceed 1"},
+            "roofline": roof,
         }
-        out["warm_start"] = warm
+        if warm is not None:
+            out["warm_start"] = warm
+        if sweep is not None:
+            out["gate_sweep"] = sweep
         if episode is not None:
             out["episode"] = episode
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):      # HBM bytes per launch from a separate rocprofv3 --pmc run
-            tr = json.load(open(tfile))
-            if tr.get("workload") == out["config"]["workload"]:
-                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = tr["source"]
         ifile = os.path.join(ROOT, "profiles", "issue_stats.json")
         if os.path.exists(ifile):      # what actually bounds the LDS-resident kernel (PMC evidence)
             st = json.load(open(ifile))

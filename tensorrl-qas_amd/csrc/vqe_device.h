@@ -1214,11 +1214,32 @@ struct StagedCobyla {
   __device__ __forceinline__ double* x() const { return gmem; }
   // the optimiser's scalars as parked in the scratch (valid after start()/tell())
   __device__ __forceinline__ const double* state() const { return gmem + words - cby::kStateDoubles; }
+  // Staging copies: all loads of a thread are issued before its first store (a plain strided loop
+  // waits for every load in turn: ~5 dependent L2 round trips per call), in chunks of kStage
+  // double2 per thread.
+  static constexpr int kStage = 6;
   __device__ __forceinline__ void in() {
     if (!staged) return;
     const double2* s = (const double2*)gmem;
     double2* d = (double2*)lmem;
-    for (int i = threadIdx.x; i < (words + 1) / 2; i += kThreads) d[i] = s[i];
+    const int nw = (words + 1) / 2;
+    for (int i0 = threadIdx.x; i0 < nw; i0 += kStage * kThreads) {
+      double2 v[kStage];
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) {
+        const int i = i0 + k * kThreads;
+        v[k] = s[i < nw ? i : nw - 1];
+      }
+      // (opaque uses: left alone, the compiler sinks every load into the guarded store below and
+      // waits for it there - kStage dependent round trips)
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y));
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) {
+        const int i = i0 + k * kThreads;
+        if (i < nw) d[i] = v[k];
+      }
+    }
     __syncthreads();
   }
   __device__ __forceinline__ void out() {
@@ -1228,7 +1249,27 @@ struct StagedCobyla {
     if (!staged) return;
     const double2* s = (const double2*)lmem;
     double2* d = (double2*)gmem;
-    for (int i = threadIdx.x; i < (words + 1) / 2; i += kThreads) d[i] = s[i];
+    const int nw = (words + 1) / 2;
+    for (int i0 = threadIdx.x; i0 < nw; i0 += kStage * kThreads) {
+      double2 v[kStage];
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) {
+        const int i = i0 + k * kThreads;
+        v[k] = s[i < nw ? i : nw - 1];
+      }
+      // (opaque uses: left alone, the compiler sinks every load into the guarded store below and
+      // waits for it there - kStage dependent round trips)
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y));
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) {
+        const int i = i0 + k * kThreads;
+        if (i < nw) d[i] = v[k];
+      }
+    }
+    // every thread has its part of the staging area in registers by now (the stores above waited for
+    // the LDS reads), and whatever overwrites the state region next - the first re-layout or the
+    // final scatter of the coming evaluation, the x[] copy of the result - sits behind a barrier
     __syncthreads();
   }
   // FIRST: start() instead of tell().  The optimiser object lives only inside this call.

@@ -87,3 +87,27 @@ def test_term_owner_partitions():
             assert len(set(own[hh.xmask == x].tolist())) == 1          # a group is never split
         sizes = [int((own == r).sum()) for r in range(world)]
         assert sum(sizes) == 77
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` with no launcher in the environment must start the two ranks itself
+    (a child `python -m torch.distributed.run`, spawned before anything touches the GPU) and rank 0
+    prints one JSON line carrying the world size it saw.  CPU rehearsal of that path: --selftest-launch
+    does the rendezvous and one all-reduce over gloo, no GPU work."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--selftest-launch"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["ranks_seen"] == 2 and out["n_gpus"] == 2 and out["backend"] == "gloo" and out["rank_sum"] == 3.0
+    # a world size that contradicts --gpus is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                       capture_output=True, text=True, env=env2, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
