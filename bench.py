@@ -161,12 +161,14 @@ def cpu_baseline(tq, ham, psi0, batch, G, n_steps, maxfun, one_thread_evals=400)
             "nproc": int(nproc), "cpu_model": model, "blas": blas}
 
 
-def episode_aux(tq, torch, dev, num_envs, max_steps, barrier=None, seed0=0):
+def episode_aux(tq, torch, dev, num_envs, max_steps, barrier=None, seed0=0, native=True):
     """The named configuration itself: TensorRL_fixed/LIH12q_TNbond2 (137 layers, 110 steps per
-    episode, COBYLA maxiter 1000) through VecCircuitEnv with a uniformly random legal policy -
-    warm-started COBYLA exactly as in the reference's episodes.  Data are the synthetic LiH-12q
-    stand-ins (tensorrl_qas_amd.synthetic).  Reports the wall rate (Python host bookkeeping of
-    every environment included) and the rate of the device part alone."""
+    episode, COBYLA maxiter 1000) through VecCircuitEnv - the env.step() / reset() surface the DeepQ
+    driver calls - with a uniformly random legal policy: warm-started COBYLA exactly as in the
+    reference's episodes.  Data are the synthetic LiH-12q stand-ins (tensorrl_qas_amd.synthetic).
+    Host side: the compiled loop of csrc/vec_env.cpp (one Python process); two half batches are software
+    pipelined (step_async / step_wait: the host work of one overlaps the launch of the other).
+    Reports the wall rate and the rate of the device part alone."""
     import copy
     import tempfile
     from tensorrl_qas_amd import synthetic
@@ -175,35 +177,41 @@ def episode_aux(tq, torch, dev, num_envs, max_steps, barrier=None, seed0=0):
     root = synthetic.write_lih12_dataset(tempfile.mkdtemp(prefix="lih12_"))
     conf = copy.deepcopy(synthetic.LIH12_FIXED_CONFIG)
     conf["env"]["data_root"] = root
-    # two half batches, software pipelined: the host bookkeeping of one overlaps the launch of
-    # the other (VecCircuitEnv.step_async / step_wait; each half has its own engine and stream)
     half = max(1, num_envs // 2)
-    vecs = [VecCircuitEnv(CircuitEnv, conf, torch.device(f"cuda:{dev}"), half, seed=s) for s in (seed0, seed0 + 1)]
+    vecs = [VecCircuitEnv(CircuitEnv, conf, torch.device(f"cuda:{dev}"), half, seed=s, native=native) for s in (seed0, seed0 + 1)]
     num_envs = 2 * half
-    table = vecs[0].envs[0]._actions_table
+    tdict = vecs[0]._proto._actions_table
+    table = np.array([tdict[i] for i in range(len(tdict))], np.int32)
     rng = np.random.default_rng(7 + seed0)
     for v in vecs:
         v.reset()
-    n_steps = min(max_steps, vecs[0].envs[0].num_layers_termination)
+    n_steps = min(max_steps, vecs[0]._proto.num_layers_termination)
     steps = nfev = 0
     t_gpu = 0.0
 
     def choose(vec):
-        acts = []
-        for e in vec.envs:
-            ill = set(e.illegal_action_new())
-            a = int(rng.integers(len(table)))
-            while a in ill:
-                a = int(rng.integers(len(table)))
-            acts.append(table[a])
-        return acts
+        """uniformly random LEGAL action per environment (illegal_action_new() of every environment first,
+        as the reference's driver does before each step, TensorRL_fixed_noiseless.py:118-120)"""
+        if vec.native:
+            ill = vec.illegal_actions_array()
+        else:
+            lists = vec.illegal_actions()
+            ill = np.full((vec.num_envs, vec.num_qubits), -1, np.int32)
+            for b, l in enumerate(lists):
+                ill[b, :len(l)] = l
+        a = rng.integers(0, table.shape[0], vec.num_envs)
+        bad = (ill == a[:, None]).any(axis=1)
+        while bad.any():
+            a[bad] = rng.integers(0, table.shape[0], int(bad.sum()))
+            bad = (ill == a[:, None]).any(axis=1)
+        return table[a]
 
     def collect(vec):
         nonlocal steps, nfev, t_gpu
         vec.step_wait()
         t_gpu += vec.engine.last_kernel_ms() * 1e-3
         steps += vec.num_envs
-        nfev += sum(e.nfev for e in vec.envs)
+        nfev += float(np.sum(vec.nfev))
 
     if barrier is not None:      # tools/probe_episode_procs.py: several host processes share the GPU
         barrier.wait()
@@ -217,14 +225,15 @@ def episode_aux(tq, torch, dev, num_envs, max_steps, barrier=None, seed0=0):
             vecs[0].step_async(choose(vecs[0]))      # launch A's next step while B runs
         collect(vecs[1])
     dt = time.perf_counter() - t0
-    envs = vecs[0].envs + vecs[1].envs
-    return {"workload": f"TensorRL_fixed/LIH12q_TNbond2 (synthetic data), 2 x {half} envs x {n_steps} steps, random policy, "
-                        "half batches pipelined (step_async / step_wait)",
+    rot = [float(np.mean(v._field("n_rotations"))) if v.native else
+           float(np.mean([int((e.state[:, 12:15] == 1).sum()) for e in v.envs])) for v in vecs]
+    return {"workload": f"TensorRL_fixed/LIH12q_TNbond2 (synthetic data), 2 x {half} envs x {n_steps} steps, random legal policy, "
+                        "half batches pipelined (step_async / step_wait), ONE host process",
+            "host_loop": "native (csrc/vec_env.cpp)" if vecs[0].native else "python objects",
             "env_steps_per_s_wall": steps / dt, "env_steps_per_s_device": steps / t_gpu,
             "env_steps": steps, "t_start": t_start, "t_end": t_start + dt,
             "device_note": "sum of the kernel times of both halves; their launches may overlap on the GPU",
-            "mean_nfev_per_step": nfev / steps, "mean_rotations_at_end": float(np.mean(
-                [int((e.state[:, 12:15] == 1).sum()) for e in envs]))}
+            "mean_nfev_per_step": nfev / steps, "mean_rotations_at_end": float(np.mean(rot))}
 
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64, vector = matrix rate (half of the guide's 157.3 TF FP32 vector figure)
@@ -444,7 +453,7 @@ def main():
     ap.add_argument("--no-episode", action="store_true", help="skip the LIH12q fixed config through VecCircuitEnv")
     ap.add_argument("--episode", action="store_true", help="(default at N = 1; kept for older command lines)")
     ap.add_argument("--episode-envs", type=int, default=2048)
-    ap.add_argument("--episode-steps", type=int, default=24)
+    ap.add_argument("--episode-steps", type=int, default=110)
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' "
                     "only to rehearse the multi-rank code path on a box with fewer GPUs than ranks")

@@ -56,6 +56,35 @@ SIGNATURES = {
     "vqe_cobyla_destroy": (None, [vp]),
 }
 
+
+
+class VecEnvConfig(C.Structure):
+    """vqe_vecenv_config_t of include/vqe_env.h"""
+    _fields_ = [("n_qubits", C.c_int32), ("num_layers", C.c_int32), ("num_envs", C.c_int32), ("layer_offset", C.c_int32),
+                ("noisy", C.c_int32), ("num_layers_termination", C.c_int32), ("maxfun", C.c_int32),
+                ("min_eig", C.c_double), ("accept_err", C.c_double),
+                ("n_thresholds", C.c_int32), ("thresholds", c_f64p), ("switch_episodes", c_i64p),
+                ("n_init_gates", C.c_int32), ("init_layer", c_i32p), ("init_kind", c_i32p), ("init_q0", c_i32p),
+                ("init_q1", c_i32p), ("init_angle", C.POINTER(C.c_float)), ("init_energy", C.c_double),
+                ("n_actions", C.c_int32), ("action_table", c_i32p)]
+
+
+# include/vqe_env.h (same shared library)
+SIGNATURES.update({
+    "vqe_vecenv_create": (C.c_int, [C.POINTER(VecEnvConfig), vp, C.POINTER(vp)]),
+    "vqe_vecenv_destroy": (None, [vp]),
+    "vqe_vecenv_last_error": (C.c_char_p, [vp]),
+    "vqe_vecenv_reset": (C.c_int, [vp, C.c_int32, c_i32p, c_i32p]),
+    "vqe_vecenv_illegal_actions": (C.c_int, [vp, c_i32p]),
+    "vqe_vecenv_step_begin": (C.c_int, [vp, c_i32p]),
+    "vqe_vecenv_step_end": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), c_i32p, c_i64p]),
+    "vqe_vecenv_get": (C.c_int, [vp, C.c_int, c_f64p]),
+    "vqe_vecenv_state": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_float)]),
+    "vqe_vecenv_moments": (C.c_int, [vp, C.c_int32, c_i32p, c_i32p]),
+    "vqe_vecenv_opt_ang": (C.c_int, [vp, C.c_int32, c_f64p, c_i32p]),
+    "vqe_vecenv_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+})
+
 # include/mps2qc_hip.h (libmps2qc_hip.so: the offline MPS -> PQC fit)
 MPS2QC_LIB_PATH = os.environ.get("MPS2QC_HIP_LIB") or os.path.join(_HERE, "libmps2qc_hip.so")
 MPS2QC_SIGNATURES = {

@@ -15,9 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    text = open(os.path.join(ROOT, "include", "vqe_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(vqe_[a-z_0-9]+)\s*\(", text)))
+    names = set()
+    for header in ("vqe_hip.h", "vqe_env.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(vqe_[a-z_0-9]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -27,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     names = _declared()
     assert len(names) >= 30
     for name in names:
-        assert hasattr(lib, name), f"{name} declared in vqe_hip.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
 

@@ -149,7 +149,11 @@ def test_noisy_env_smoke(data_root):
         assert torch.isfinite(rwd)
 
 
-def test_vec_env_equals_single_envs(data_root):
+@pytest.mark.parametrize("native", [True, False])
+def test_vec_env_equals_single_envs(data_root, native):
+    """Both host loops of VecCircuitEnv - the compiled one (csrc/vec_env.cpp) and the per-environment
+    Python objects - against B independent CircuitEnv instances: observations, rewards, dones, energies,
+    nfev and the dense state tensors are identical."""
     from tensorrl_qas_amd.environments.environment_qulacs_TN_notin_agent import CircuitEnv
     from tensorrl_qas_amd.environments.vec_env import VecCircuitEnv
     from tensorrl_qas_amd.environments.utils.utils import dictionary_of_actions
@@ -157,7 +161,8 @@ def test_vec_env_equals_single_envs(data_root):
     conf["non_local_opt"]["global_iters"] = 120
     dev = torch.device("cuda:0")
     B = 5
-    vec = VecCircuitEnv(CircuitEnv, conf, dev, B)
+    vec = VecCircuitEnv(CircuitEnv, conf, dev, B, native=native)
+    assert vec.native == native
     obs = vec.reset()
     assert obs.shape[0] == B
     table = dictionary_of_actions(6)
@@ -173,6 +178,66 @@ def test_vec_env_equals_single_envs(data_root):
             assert torch.equal(o[b], o1) and float(r[b]) == float(r1) and d[b] == d1
             assert vec.envs[b].energy == e.energy and vec.envs[b].nfev == e.nfev
             assert torch.equal(vec.envs[b].state, e.state)
+            assert list(vec.envs[b].moments) == list(e.moments)
+            assert np.array_equal(np.asarray(vec.envs[b].opt_ang_save), np.asarray(e.opt_ang_save))
+
+
+@pytest.mark.parametrize("cfg,module,steps", [
+    ("TensorRL_fixed/H2O8q_TNbond2", "environment_qulacs_TN_notin_agent", 9),
+    ("TensorRL_trainable/heisenberg_5q_TNbond2", "environment_qulacs", 4),
+    ("StructureRL/heisenberg_5q_TNbond2", "environment_qulacs", 5),
+    ("TensorRL_fixed/H2O8q_TNbond2_noise", "environment_qulacs_TN_notin_agent_noise", 5),
+    ("TensorRL_fixed/heisenberg_5q_TNbond2", "environment_qulacs_TN_notin_agent", 44),
+])
+def test_native_host_loop_equals_python_host_loop(data_root, cfg, module, steps):
+    """The compiled host loop against the Python one on every environment flavour (fixed, trainable with
+    the encoded init circuit, zero-parameter StructureRL, Pauli noise, and a whole 5-qubit episode down
+    to the depth budget incl. reset): same engine calls in the same order, so everything - illegal lists
+    and slots, observations, rewards, dones, energies, errors, nfev, thresholds, states - is identical."""
+    import importlib
+    from tensorrl_qas_amd.environments.vec_env import VecCircuitEnv
+    cls = importlib.import_module("tensorrl_qas_amd.environments." + module).CircuitEnv
+    conf = reference_config(cfg, data_root)
+    conf["non_local_opt"]["global_iters"] = 60
+    dev = torch.device("cuda:0")
+    B = 6
+    vn = VecCircuitEnv(cls, conf, dev, B, seed=4, native=True)
+    vp = VecCircuitEnv(cls, conf, dev, B, seed=4, native=False)
+    assert vn.native and not vp.native
+    on, op = vn.reset(), vp.reset()
+    assert torch.equal(on, op)
+    if cls.NOISY:      # reset() of the Python loop evaluates B energies, the native one none: align the trajectory counters
+        for v in (vn, vp):
+            v.engine.set_noise(cls.NOISE_P1, cls.NOISE_P2, 4)
+    table = vp.envs[0]._actions_table
+    rng = np.random.default_rng(17)
+    for t in range(steps):
+        ill_n, ill_p = vn.illegal_actions(), vp.illegal_actions()
+        assert ill_n == ill_p, t
+        acts = []
+        for b in range(B):
+            a = int(rng.integers(len(table)))
+            while a in ill_p[b] and rng.random() < 0.8:       # mostly legal, sometimes not (occupied slots, repeats)
+                a = int(rng.integers(len(table)))
+            acts.append(table[a])
+        on, rn, dn = vn.step(acts)
+        op, rp, dp = vp.step(acts)
+        assert torch.equal(on, op) and torch.equal(rn, rp) and dn == dp, t
+        for b in range(B):
+            e = vp.envs[b]
+            w = vn.envs[b]
+            assert (w.energy, w.error, w.nfev, w.step_counter, w.done_threshold) == \
+                (e.energy, e.error, e.nfev, e.step_counter, e.done_threshold)
+            assert float(w.prev_energy) == float(e.prev_energy) and w.rwd == float(e.rwd)
+            assert torch.equal(w.state, e.state)
+            assert list(w.moments) == list(e.moments) and w.illegal_actions == [list(s) for s in e.illegal_actions]
+            assert w.lowest_energy == e.curriculum.lowest_energy
+        if any(dn):
+            idx = [b for b in range(B) if dn[b]]
+            assert torch.equal(vn.reset(idx), vp.reset(idx))
+            for b in idx:
+                assert vn.envs[b].step_counter == -1 and float(vn.envs[b].prev_energy) == float(vp.envs[b].prev_energy)
+                assert vn.envs[b].episodes_completed == vp.envs[b].curriculum.episodes_completed == 1
 
 
 def test_restricted_shot_noise_env(data_root):
