@@ -11,6 +11,8 @@
 // (vqe_cobyla ask/tell) because with Pauli-term sharding every evaluation ends in a
 // collective.
 #pragma once
+#include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "vqe_device.h"
@@ -27,9 +29,20 @@ struct StreamWork {
   uint32_t* tzp = nullptr;    size_t tzp_cap = 0;      // [batch][n_terms] physical Z masks
   double* tsg = nullptr;      size_t tsg_cap = 0;      // [batch][n_terms] (-1)^{z.c}
   double* partial = nullptr;  size_t partial_cap = 0;  // [batch][blocks]
+  // LDS-tiled kernels (vqe_tile.h)
+  void* passes = nullptr;     size_t passes_cap = 0;   // TilePass [batch][max_pass]
+  void* opc = nullptr;        size_t opc_cap = 0;      // OpCoord [batch][max_ops]
+  int32_t* npass = nullptr;   size_t npass_cap = 0;    // [batch] op passes, [batch] energy passes
+  void* epasses = nullptr;    size_t epasses_cap = 0;  // TilePass [batch][kMaxEnergyPasses]
+  int32_t* eorder = nullptr;  size_t eorder_cap = 0;   // [batch][n_groups] group ids pass by pass, then [batch][n_groups] pass of a group
+  uint32_t* gcx = nullptr;    size_t gcx_cap = 0;      // [batch][n_groups]
+  void* trec = nullptr;       size_t trec_cap = 0;     // TermRec [batch][n_terms]
+  int32_t* grec = nullptr;    size_t grec_cap = 0;     // [batch][n_groups]
   ~StreamWork() {
     (void)hipFree(states); (void)hipFree(ops); (void)hipFree(masks); (void)hipFree(meta);
     (void)hipFree(cs); (void)hipFree(gxp); (void)hipFree(tzp); (void)hipFree(tsg); (void)hipFree(partial);
+    (void)hipFree(passes); (void)hipFree(opc); (void)hipFree(npass); (void)hipFree(epasses); (void)hipFree(eorder);
+    (void)hipFree(gcx); (void)hipFree(trec); (void)hipFree(grec);
   }
 };
 
@@ -370,6 +383,10 @@ __global__ void __launch_bounds__(kThreads) k_s_state_out(BatchArgs A, const dou
   A.state_out[i] = a;
 }
 
+}  // namespace vqe
+#include "vqe_tile.h"
+namespace vqe {
+
 #define SW_TRY(expr)                                                            \
   do {                                                                          \
     hipError_t _e = (expr);                                                     \
@@ -379,7 +396,15 @@ __global__ void __launch_bounds__(kThreads) k_s_state_out(BatchArgs A, const dou
     }                                                                           \
   } while (0)
 
-// circuit + (partial) energy of every resident stream, results in A.fout (device)
+// circuit + (partial) energy of every resident stream, results in A.fout (device).
+// Default: the LDS-tiled kernels of vqe_tile.h; VQE_STREAM_TILED=0 (or a Hamiltonian shard with too many
+// X-mask groups for the pass table) selects the one-sweep-per-four-ops kernels above.
+inline bool stream_tiled(int n_groups, int n_terms) {
+  static const bool env_on = [] { const char* e = getenv("VQE_STREAM_TILED"); return !(e && e[0] == '0'); }();
+  return env_on && (n_groups + kTileFree - 1) / kTileFree + 1 <= kMaxEnergyPasses &&
+         sizeof(double2) * kTileAmps + sizeof(TermLds) * (size_t)(n_terms > 0 ? n_terms : 1) <= 160 * 1024;
+}
+
 inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipStream_t st,
                            uint64_t eval_id, bool want_energy, std::string& err, bool want_circuit = true) {
   const size_t dim = (size_t)1 << A.n;
@@ -393,7 +418,58 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
   SW_TRY(sw_reserve(sw.gxp, sw.gxp_cap, (size_t)B * ng));
   SW_TRY(sw_reserve(sw.tzp, sw.tzp_cap, (size_t)B * nt));
   SW_TRY(sw_reserve(sw.tsg, sw.tsg_cap, (size_t)B * nt));
-  const int eblk = (int)(dim / (kThreads * kEnergyApt)) / (A.amp_world > 0 ? A.amp_world : 1);
+  const int world = A.amp_world > 0 ? A.amp_world : 1;
+  const bool tiled = stream_tiled(A.ham.n_groups, n_terms);
+  if (tiled) {
+    const int tiles = (int)(dim >> kTileBits);
+    const int max_pass = A.max_ops / kTileFree + 2;          // a pass is closed by its (kTileFree + 1)-th independent mask
+    const int e_pass = std::min(kMaxEnergyPasses, (A.ham.n_groups + kTileFree - 1) / kTileFree + 1);
+    {
+      TilePass* tp = (TilePass*)sw.passes; size_t cap = sw.passes_cap;
+      SW_TRY(sw_reserve(tp, cap, (size_t)B * max_pass)); sw.passes = tp; sw.passes_cap = cap;
+      OpCoord* oc = (OpCoord*)sw.opc; cap = sw.opc_cap;
+      SW_TRY(sw_reserve(oc, cap, (size_t)B * A.max_ops)); sw.opc = oc; sw.opc_cap = cap;
+      tp = (TilePass*)sw.epasses; cap = sw.epasses_cap;
+      SW_TRY(sw_reserve(tp, cap, (size_t)B * kMaxEnergyPasses)); sw.epasses = tp; sw.epasses_cap = cap;
+    }
+    SW_TRY(sw_reserve(sw.npass, sw.npass_cap, (size_t)2 * B));
+    SW_TRY(sw_reserve(sw.eorder, sw.eorder_cap, (size_t)2 * B * ng));
+    SW_TRY(sw_reserve(sw.gcx, sw.gcx_cap, (size_t)B * ng));
+    {
+      TermRec* tr = (TermRec*)sw.trec; size_t cap = sw.trec_cap;
+      SW_TRY(sw_reserve(tr, cap, (size_t)B * nt)); sw.trec = tr; sw.trec_cap = cap;
+    }
+    SW_TRY(sw_reserve(sw.grec, sw.grec_cap, (size_t)B * ng));
+    const int tiles_rank = tiles / world;
+    SW_TRY(sw_reserve(sw.partial, sw.partial_cap, (size_t)B * e_pass * tiles_rank));
+    if (want_circuit) {
+      hipLaunchKernelGGL(k_s_compile, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.masks, sw.meta, eval_id);
+      hipLaunchKernelGGL(k_s_sincos, dim3((A.max_params + 63) / 64, B), dim3(64), 0, st, A, sw.cs);
+      hipLaunchKernelGGL(k_t_plan_ops, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.meta, (TilePass*)sw.passes,
+                         (OpCoord*)sw.opc, sw.npass, max_pass);
+      for (int p = 0; p < max_pass; ++p)
+        hipLaunchKernelGGL(k_t_ops, dim3((unsigned)tiles, B), dim3(kThreads), 0, st, A, sw.states, sw.ops,
+                           (const OpCoord*)sw.opc, sw.cs, (const TilePass*)sw.passes, sw.npass, p, max_pass);
+    }
+    if (want_energy) {
+      const int m = std::max(nt, ng);
+      hipLaunchKernelGGL(k_s_terms, dim3((m + 63) / 64, B), dim3(64), 0, st, A, sw.masks, sw.meta, n_terms,
+                         sw.gxp, sw.tzp, sw.tsg);
+      hipLaunchKernelGGL(k_t_plan_energy, dim3((B + 63) / 64), dim3(64), 0, st, A, n_terms, sw.gxp, sw.tzp, sw.tsg,
+                         (TilePass*)sw.epasses, sw.npass + B, sw.eorder, sw.gcx, sw.grec, (TermRec*)sw.trec,
+                         sw.eorder + (size_t)B * ng);
+      const size_t elds = sizeof(double2) * kTileAmps + sizeof(TermLds) * (size_t)nt;
+      SW_TRY(hipFuncSetAttribute((const void*)k_t_energy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
+      hipLaunchKernelGGL(k_t_energy, dim3((unsigned)tiles_rank, B, e_pass), dim3(kThreads), elds, st, A, sw.states, n_terms,
+                         (const TilePass*)sw.epasses, sw.npass + B, sw.eorder, sw.gcx, sw.grec, (const TermRec*)sw.trec,
+                         sw.partial);
+      hipLaunchKernelGGL(k_s_reduce, dim3(B), dim3(kThreads), 0, st, sw.partial, e_pass * tiles_rank, A.fout, A.noise,
+                         eval_id, A.amp_rank == 0 ? 1 : 0);
+    }
+    SW_TRY(hipGetLastError());
+    return 0;
+  }
+  const int eblk = (int)(dim / (kThreads * kEnergyApt)) / world;
   SW_TRY(sw_reserve(sw.partial, sw.partial_cap, (size_t)B * eblk));
 
   if (want_circuit) {
