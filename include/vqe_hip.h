@@ -141,7 +141,8 @@ int vqe_batch_run_reduction(vqe_t* h);
  * channel construct_ansatz attached to it (VQE_qulacs_TN_notin_RL_noise.py:26-28,40-50) and is
  * left out of the optimised circuit with it; the noise draws of the COBYLA phase are numbered by
  * gate position in that pre-action circuit, those of the final evaluation by position in the
- * full one. */
+ * full one.  n <= 13: one fused launch; n >= 14 (streaming path): the same steps with the COBYLA loop
+ * driven by the host over batched evaluations. */
 int vqe_batch_set_new_gate(vqe_t* h, const int32_t* new_gate /* batch, or NULL */);
 int vqe_batch_run_env_step(vqe_t* h, double rhobeg, double rhoend, int maxfun);
 int vqe_batch_fetch(vqe_t* h, double* x /* sum of n_params, may be NULL */,

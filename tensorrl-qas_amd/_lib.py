@@ -5,6 +5,16 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# Load order matters: PyTorch-ROCm ships its own copy of the HIP runtime (torch/lib/libamdhip64.so) while
+# libvqe_hip.so is linked against the system one (/opt/rocm/lib).  With torch imported FIRST both sides
+# share one initialised runtime; the other way round torch finds "No HIP GPUs" later
+# (tools/probe_torch_after.py).  PyTorch is this package's plumbing for device tensors and
+# torch.distributed anyway, so import it before the library whenever it is installed.
+try:
+    import torch  # noqa: F401
+except ImportError:      # the engine itself needs only the HIP runtime
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQE_HIP_LIB") or os.path.join(_HERE, "libvqe_hip.so")  # override for kernel experiments
 

@@ -77,6 +77,15 @@ struct vqe_handle {
   DevBuf<int32_t> d_gate_count, d_par_count, d_nfev, d_new_gate, d_order;
   bool has_new_gate = false;
   std::vector<int32_t> h_gate_count;
+  // host copy of the resident batch (the streaming path builds the pre-action circuits of an env-step from it)
+  std::vector<GateRec> h_gates;
+  std::vector<int64_t> h_gate_begin;
+  std::vector<double> h_theta;
+  std::vector<int32_t> h_new_gate;
+  // streaming env-step: the pre-action batch (device)
+  DevBuf<GateRec> d_gates2;
+  DevBuf<int64_t> d_gate_begin2, d_par_begin2;
+  DevBuf<int32_t> d_gate_count2, d_par_count2;
   DevBuf<double> d_theta, d_x, d_xraw, d_f, d_scratch;
   DevBuf<double2> d_state;
   DevBuf<unsigned long long> d_dbg;
@@ -497,6 +506,9 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   h->h_par_begin = pbeg;
   h->h_par_count = pcnt;
   h->h_gate_count = gcnt;
+  h->h_gates = gates;
+  h->h_gate_begin = gbeg;
+  h->h_theta.assign(theta0, theta0 + total_params);
   h->has_new_gate = false;
   return VQE_OK;
 }
@@ -514,6 +526,38 @@ int ready(vqe_t* h) {
   if (!h) return VQE_EINVAL;
   if (!h->ham_set) return fail(h, VQE_ESTATE, "vqe_set_hamiltonian_pauli has not been called");
   if (h->batch <= 0) return fail(h, VQE_ESTATE, "no circuits loaded");
+  return VQE_OK;
+}
+
+// Host-driven COBYLA of all resident streams in lock-step (one batched evaluation per iteration): the
+// streaming path's form of scipy.optimize.minimize(..., method='COBYLA') (environment_qulacs_TN_notin_agent.py:478).
+// x: in x0, out the result (layout pbeg / pcnt); trial points travel through d_x.
+int stream_cobyla(vqe_t* h, BatchArgs& A, const std::vector<int64_t>& pbeg, const std::vector<int32_t>& pcnt,
+                  std::vector<double>& x, std::vector<double>& f, std::vector<int32_t>& nfev) {
+  const int B = h->batch;
+  std::vector<vqe_cobyla_t*> cob(B, nullptr);
+  struct Guard { std::vector<vqe_cobyla_t*>& v; ~Guard() { for (auto* c : v) vqe_cobyla_destroy(c); } } guard{cob};
+  for (int b = 0; b < B; ++b)
+    if (vqe_cobyla_create(pcnt[b], x.data() + pbeg[b], A.rhobeg, A.rhoend, A.maxfun, &cob[b]))
+      return fail(h, VQE_ENOMEM, "host COBYLA allocation failed");
+  HIP_TRY(h, h->d_x.reserve(x.size() + 1));
+  uint64_t it = 0;
+  int rc = 0;
+  for (;;) {
+    int active = 0;
+    for (int b = 0; b < B; ++b) active += vqe_cobyla_ask(cob[b], x.data() + pbeg[b]) == 1;
+    if (!active) break;
+    if (!x.empty())
+      HIP_TRY(h, hipMemcpyAsync(h->d_x.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
+    A.theta = h->d_x.p;  // trial points live in the output buffer; x0 stays untouched
+    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base + (++it), true, h->err);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(f.data(), h->d_f.p, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int b = 0; b < B; ++b)
+      if (vqe_cobyla_ask(cob[b], nullptr) == 1) vqe_cobyla_tell(cob[b], f[b]);
+  }
+  for (int b = 0; b < B; ++b) vqe_cobyla_result(cob[b], x.data() + pbeg[b], &f[b], &nfev[b], nullptr);
   return VQE_OK;
 }
 
@@ -535,39 +579,86 @@ int stream_run(vqe_t* h, int which, BatchArgs& A) {
                          h->sw.states, h->sw.masks, h->sw.meta);
       HIP_TRY(h, hipGetLastError());
     }
-  } else {
+  } else if (which == 1) {
     const int B = h->batch;
-    std::vector<double> x((size_t)h->total_params), f(B, 0.0), flast(B, 0.0);
-    if (h->total_params)
-      HIP_TRY(h, hipMemcpyAsync(x.data(), h->d_theta.p, x.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    std::vector<vqe_cobyla_t*> cob(B, nullptr);
-    struct Guard { std::vector<vqe_cobyla_t*>& v; ~Guard() { for (auto* c : v) vqe_cobyla_destroy(c); } } guard{cob};
-    for (int b = 0; b < B; ++b)
-      if (vqe_cobyla_create(h->h_par_count[b], x.data() + h->h_par_begin[b], A.rhobeg, A.rhoend, A.maxfun, &cob[b]))
-        return fail(h, VQE_ENOMEM, "host COBYLA allocation failed");
-    uint64_t it = 0;
-    for (;;) {
-      int active = 0;
-      for (int b = 0; b < B; ++b) active += vqe_cobyla_ask(cob[b], x.data() + h->h_par_begin[b]) == 1;
-      if (!active) break;
-      if (h->total_params)
-        HIP_TRY(h, hipMemcpyAsync(h->d_x.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
-      A.theta = h->d_x.p;  // trial points live in the output buffer; x0 stays untouched
-      rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base + (++it), true, h->err);
-      if (rc) return rc;
-      HIP_TRY(h, hipMemcpyAsync(f.data(), h->d_f.p, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(h, hipStreamSynchronize(h->stream));
-      for (int b = 0; b < B; ++b)
-        if (vqe_cobyla_ask(cob[b], nullptr) == 1) vqe_cobyla_tell(cob[b], f[b]);
-    }
+    std::vector<double> x(h->h_theta), f(B, 0.0);
     std::vector<int32_t> nfev(B);
-    for (int b = 0; b < B; ++b) vqe_cobyla_result(cob[b], x.data() + h->h_par_begin[b], &f[b], &nfev[b], nullptr);
+    rc = stream_cobyla(h, A, h->h_par_begin, h->h_par_count, x, f, nfev);
+    if (rc) return rc;
     if (h->total_params)
       HIP_TRY(h, hipMemcpyAsync(h->d_x.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_f.p, f.data(), (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_nfev.p, nfev.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+  } else {
+    // which == 3: one CircuitEnv.step() per stream on the streaming path
+    // (environment_qulacs_TN_notin_agent.py:283-291): host-driven COBYLA on the PRE-action circuits (the new
+    // gate and the noise channel attached to it left out, its angle not a variable), float32 round trip,
+    // then the full circuits.
+    const int B = h->batch;
+    std::vector<GateRec> g2;
+    std::vector<int64_t> gbeg2(B), pbeg2(B);
+    std::vector<int32_t> gcnt2(B), pcnt2(B), hole(B, -1);
+    std::vector<double> x0;
+    g2.reserve(h->h_gates.size());
+    for (int b = 0; b < B; ++b) {
+      const int64_t g0 = h->h_gate_begin[b];
+      const int G = h->h_gate_count[b];
+      const int skip = h->has_new_gate ? h->h_new_gate[b] : -1;
+      int skip_end = skip + 1;
+      if (skip >= 0) {
+        const GateRec r = h->h_gates[g0 + skip];
+        if (r.kind >= G_RX && r.kind <= G_RZ) hole[b] = r.pidx;
+        if (skip + 1 < G) {
+          const GateRec fo = h->h_gates[g0 + skip + 1];
+          if ((fo.kind == G_DEPOL1 && r.kind >= G_RX && r.kind <= G_RZ && fo.q0 == r.q0) ||
+              (fo.kind == G_DEPOL2 && r.kind == G_CNOT && fo.q0 == r.q0 && fo.q1 == r.q1))
+            skip_end = skip + 2;
+        }
+      }
+      gbeg2[b] = (int64_t)g2.size();
+      pbeg2[b] = (int64_t)x0.size();
+      for (int i = 0; i < G; ++i) {
+        if (i >= skip && i < skip_end) continue;
+        GateRec r = h->h_gates[g0 + i];
+        if (r.kind >= G_RX && r.kind <= G_RZ && hole[b] >= 0 && r.pidx > hole[b]) r.pidx -= 1;
+        g2.push_back(r);
+      }
+      gcnt2[b] = (int32_t)((int64_t)g2.size() - gbeg2[b]);
+      for (int j = 0; j < h->h_par_count[b]; ++j)
+        if (j != hole[b]) x0.push_back(h->h_theta[h->h_par_begin[b] + j]);
+      pcnt2[b] = (int32_t)((int64_t)x0.size() - pbeg2[b]);
+    }
+    int rc2;
+    if ((rc2 = upload(h, h->d_gates2, g2.data(), g2.size()))) return rc2;
+    if ((rc2 = upload(h, h->d_gate_begin2, gbeg2.data(), gbeg2.size()))) return rc2;
+    if ((rc2 = upload(h, h->d_gate_count2, gcnt2.data(), gcnt2.size()))) return rc2;
+    if ((rc2 = upload(h, h->d_par_begin2, pbeg2.data(), pbeg2.size()))) return rc2;
+    if ((rc2 = upload(h, h->d_par_count2, pcnt2.data(), pcnt2.size()))) return rc2;
+    BatchArgs A2 = A;
+    A2.gates = h->d_gates2.p; A2.gate_begin = h->d_gate_begin2.p; A2.gate_count = h->d_gate_count2.p;
+    A2.par_begin = h->d_par_begin2.p; A2.par_count = h->d_par_count2.p;
+    std::vector<double> f(B, 0.0);
+    std::vector<int32_t> nfev(B);
+    rc = stream_cobyla(h, A2, pbeg2, pcnt2, x0, f, nfev);
+    if (rc) return rc;
+    std::vector<double> xraw(h->h_theta), xr32(h->h_theta);
+    for (int b = 0; b < B; ++b) {
+      int k = 0;
+      for (int j = 0; j < h->h_par_count[b]; ++j) {
+        const double v = j == hole[b] ? h->h_theta[h->h_par_begin[b] + j] : x0[pbeg2[b] + k++];
+        xraw[h->h_par_begin[b] + j] = v;
+        xr32[h->h_par_begin[b] + j] = (double)(float)v;
+      }
+    }
+    if (h->total_params) {
+      HIP_TRY(h, hipMemcpyAsync(h->d_x.p, xr32.data(), xr32.size() * 8, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipMemcpyAsync(h->d_xraw.p, xraw.data(), xraw.size() * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_nfev.p, nfev.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));      // host vectors stay alive until the copies are done
+    A.theta = h->d_x.p;
+    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base + (uint64_t)A.maxfun + 1, true, h->err);
   }
   if (rc) return rc;
   HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
@@ -583,9 +674,9 @@ int run(vqe_t* h, int which, double rhobeg, double rhoend, int maxfun) {
     which = 1;
     A.env_step = 1;
     A.new_gate = h->has_new_gate ? h->d_new_gate.p : nullptr;
-    if (!h->lds_path) return fail(h, VQE_ESTATE, "the fused env-step launch serves the LDS-resident path (n <= 13)");
+    if (!h->lds_path) which = 3;      // streaming path: host-driven loop in stream_run
   }
-  if (which == 1 && (h->shard_world > 1 || h->amp_world > 1))
+  if ((which == 1 || which == 3) && (h->shard_world > 1 || h->amp_world > 1))
     return fail(h, VQE_ESTATE, "term-sharded handles hold partial energies: drive COBYLA with "
                                "vqe_cobyla_ask/tell and sum the partial energies of all ranks");
   if (which == 4 && h->lds_path)
@@ -601,7 +692,7 @@ int run(vqe_t* h, int which, double rhobeg, double rhoend, int maxfun) {
   else rc = stream_run(h, which, A);
   if (rc) return rc;
   // every evaluation of a stochastic run consumes fresh trajectory numbers
-  if (which != 4) h->noise.eval_base += (which == 1 ? (uint64_t)maxfun + 1 : 1);
+  if (which != 4) h->noise.eval_base += ((which == 1 || which == 3) ? (uint64_t)maxfun + 1 : 1);
   return VQE_OK;
 }
 
@@ -871,6 +962,7 @@ int vqe_batch_set_new_gate(vqe_t* h, const int32_t* new_gate) {
   HIP_TRY(h, hipSetDevice(h->dev));
   int rc = upload(h, h->d_new_gate, new_gate, (size_t)h->batch);
   if (rc) return rc;
+  h->h_new_gate.assign(new_gate, new_gate + h->batch);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->has_new_gate = true;
   return VQE_OK;
@@ -899,7 +991,6 @@ int vqe_batch_fetch_xopt(vqe_t* h, double* x) {
   if (!h) return VQE_EINVAL;
   if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
   if (!x && h->total_params) return fail(h, VQE_EINVAL, "x is NULL");
-  if (!h->lds_path) return fail(h, VQE_ESTATE, "unrounded optimum is kept by the LDS-resident path only");
   HIP_TRY(h, hipSetDevice(h->dev));
   if (h->total_params)
     HIP_TRY(h, hipMemcpyAsync(x, h->d_xraw.p, (size_t)h->total_params * 8, hipMemcpyDeviceToHost, h->stream));

@@ -128,6 +128,115 @@ def heisenberg(n):
     return PauliHamiltonian(n, xs, zs, np.ones(len(strings)), label=f"heisenberg_{n}q"), strings
 
 
+def tfim(n, j=1.0, h=0.001):
+    """Open transverse-field Ising chain -J sum_i Z_i Z_{i+1} - h sum_i X_i with the term order of the
+    reference's shipped fixture (dmrg-to-qc/mol_data/tfim_j1_h0.001_6q.npz: n-1 ZZ bonds, then n X
+    fields).  2n-1 terms."""
+    strings = []
+    for i in range(n - 1):
+        s = ["I"] * n
+        s[i] = s[i + 1] = "Z"
+        strings.append("".join(s))
+    for i in range(n):
+        s = ["I"] * n
+        s[i] = "X"
+        strings.append("".join(s))
+    xs, zs = masks_from_strings(strings, n)      # the chain is reversal symmetric
+    w = np.array([-float(j)] * (n - 1) + [-float(h)] * n)
+    return PauliHamiltonian(n, xs, zs, w, label=f"tfim_j{j:g}_h{h:g}_{n}q"), strings
+
+
+def pauli_strings(ham):
+    """Pauli strings (character k = simulator qubit k) of a PauliHamiltonian."""
+    out = []
+    for x, z in zip(ham.xmask, ham.zmask):
+        x, z = int(x), int(z)
+        out.append("".join("IXZY"[((x >> q) & 1) | (((z >> q) & 1) << 1)] for q in range(ham.n)))
+    return out
+
+
+def apply(ham, psi):
+    """H |psi> from the Pauli form (no matrix): P|i> = i^{#Y} (-1)^{popc(i & z)} |i ^ x>."""
+    psi = np.asarray(psi, np.complex128)
+    idx = np.arange(psi.size, dtype=np.int64)
+    out = np.zeros_like(psi)
+    for x, z, w in zip(ham.xmask, ham.zmask, ham.coeff):
+        x, z = int(x), int(z)
+        par = idx & z
+        for s in (32, 16, 8, 4, 2, 1):
+            par ^= par >> s
+        ph = (1j ** bin(x & z).count("1")) * w
+        v = np.where(par & 1, -ph, ph) * psi
+        out[idx ^ x] += v
+    return out
+
+
+def extreme_eigenvalues(ham, tol=1e-10):
+    """(min, max) eigenvalue of a PauliHamiltonian by matrix-free Lanczos (scipy ``eigsh`` on a
+    LinearOperator that applies the Pauli sum): replaces the reference's dense ``eigvals`` - the
+    ``min_eig`` the environments subtract (environment_qulacs_TN_notin_agent.py:126-131,166-167) - where a
+    2^n x 2^n matrix cannot exist (20 qubits).  Real symmetric Hamiltonians (even #Y in every term) run in
+    real arithmetic."""
+    from scipy.sparse.linalg import LinearOperator, eigsh
+    dim = 1 << ham.n
+    idx = np.arange(dim, dtype=np.int64)
+    real = all(bin(int(x) & int(z)).count("1") % 2 == 0 for x, z in zip(ham.xmask, ham.zmask))
+    groups = {}
+    for x, z, w in zip(ham.xmask, ham.zmask, ham.coeff):
+        x, z = int(x), int(z)
+        par = idx & z
+        for s in (32, 16, 8, 4, 2, 1):
+            par ^= par >> s
+        ph = (1j ** bin(x & z).count("1")) * w
+        d = np.where(par & 1, -ph, ph)
+        groups[x] = groups.get(x, 0) + (d.real if real else d)      # one diagonal per X mask: (H v)[i ^ x] += D_x[i] v[i]
+    dtype = np.float64 if real else np.complex128
+
+    def matvec(v):
+        v = np.asarray(v, dtype).reshape(-1)
+        out = np.zeros(dim, dtype)
+        for x, d in groups.items():
+            out[idx ^ x] += d * v
+        return out
+
+    op = LinearOperator((dim, dim), matvec=matvec, dtype=dtype)
+    lo = eigsh(op, k=1, which="SA", return_eigenvectors=False, tol=tol)[0]
+    hi = eigsh(op, k=1, which="LA", return_eigenvectors=False, tol=tol)[0]
+    return float(np.real(lo)), float(np.real(hi))
+
+
+def write_npz(path, ham, eigvals=None, dense_limit=12):
+    """Hamiltonian fixture in the reference's layout (dmrg-to-qc/heisenberg_model.py:93-110,
+    making_molecules.py: keys ``hamiltonian, eigvals, weights, paulis, energy_shift``).  The dense
+    ``hamiltonian`` (big-endian np.kron order, as the reference stores it) is written up to
+    ``dense_limit`` qubits - beyond it cannot exist and the loaders of this package do not need it;
+    ``eigvals`` defaults to the full spectrum when the dense matrix is built, else to the Lanczos
+    (min, max).  ``ham`` must be in the FIXED-path convention (string character k = simulator qubit k)."""
+    strings = pauli_strings(ham)
+    out = {"weights": np.asarray(ham.coeff, np.float64), "paulis": np.array(strings), "energy_shift": 0}
+    if ham.n <= dense_limit:
+        dim = 1 << ham.n
+        idx = np.arange(dim, dtype=np.int64)
+        rev = np.zeros_like(idx)
+        for b in range(ham.n):
+            rev |= ((idx >> b) & 1) << (ham.n - 1 - b)
+        little = np.zeros((dim, dim), np.complex128)
+        for x, z, w in zip(ham.xmask, ham.zmask, ham.coeff):
+            x, z = int(x), int(z)
+            par = idx & z
+            for s in (32, 16, 8, 4, 2, 1):
+                par ^= par >> s
+            little[idx ^ x, idx] += np.where(par & 1, -1.0, 1.0) * (1j ** bin(x & z).count("1")) * w
+        out["hamiltonian"] = little[np.ix_(rev, rev)]          # np.kron (big-endian) order of the reference files
+        if eigvals is None:
+            eigvals = np.linalg.eigvalsh(little)
+    elif eigvals is None:
+        eigvals = np.array(extreme_eigenvalues(ham))
+    out["eigvals"] = np.asarray(eigvals, np.float64)
+    np.savez(path, **out)
+    return out
+
+
 def synthetic_lih12(seed=12):
     """SYNTHETIC stand-in for the 12-qubit LiH (JW, STO-3G) Hamiltonian, which the reference
     never committed.  631 real Pauli terms with Jordan-Wigner shape:

@@ -33,31 +33,12 @@ LIH12_FIXED_CONFIG = {
 
 
 def _strings(ham):
-    out = []
-    for x, z in zip(ham.xmask, ham.zmask):
-        x, z = int(x), int(z)
-        out.append("".join("IXZY"[((x >> q) & 1) | (((z >> q) & 1) << 1)] for q in range(ham.n)))
-    return np.array(out)
+    return np.array(_ham.pauli_strings(ham))
 
 
 def extreme_eigenvalues(ham):
-    """(min, max) eigenvalue of a PauliHamiltonian by sparse Lanczos (host, numpy/scipy)."""
-    from scipy.sparse import coo_matrix
-    from scipy.sparse.linalg import eigsh
-    dim = 1 << ham.n
-    idx = np.arange(dim)
-    rows, cols, vals = [], [], []
-    for x, z, w in zip(ham.xmask, ham.zmask, ham.coeff):
-        x, z = int(x), int(z)
-        par = idx & z
-        for s in (16, 8, 4, 2, 1):
-            par ^= par >> s
-        ph = (1j ** bin(x & z).count("1")) * (1.0 - 2.0 * (par & 1)) * w
-        rows.append(idx ^ x), cols.append(idx), vals.append(ph)
-    m = coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(dim, dim)).tocsr()
-    lo = eigsh(m, k=1, which="SA", return_eigenvectors=False)[0]
-    hi = eigsh(m, k=1, which="LA", return_eigenvectors=False)[0]
-    return float(np.real(lo)), float(np.real(hi))
+    """(min, max) eigenvalue by matrix-free Lanczos: see ``hamiltonian.extreme_eigenvalues``."""
+    return _ham.extreme_eigenvalues(ham)
 
 
 def init_circuit_qasm(n, seed, depth=27):
@@ -100,3 +81,41 @@ def write_lih12_dataset(root, seed=12):
     with open(os.path.join(root, "init_state_circ", f"init_{LIH12_STEM}_TNbond2.qasm"), "w") as f:
         f.write(init_circuit_qasm(12, seed))
     return root
+
+
+HEIS_FIXED_CONFIG_TEMPLATE = {      # TensorRL_fixed/heisenberg_5q_TNbond2.cfg with num_qubits / num_layers left open
+    "general": {"episodes": 10000},
+    "env": {"num_qubits": None, "num_layers": None, "err_mitig": 0, "rand_halt": 0, "n_shots": 0, "tn_init": 1,
+            "tn_bond": 2, "zero_param_init": 0, "noise_models": 0, "noise_values": 0,
+            "fn_type": "incremental_with_fixed_ends", "accept_err": 1.6e-3, "thresholds": [1.6e-3],
+            "switch_episodes": [100000], "curriculum_type": "VanillaCurriculum"},
+    "problem": {"ham_type": "heisenberg", "geometry": "", "taper": 1, "mapping": "jordan_wigner"},
+    "agent": {"angles": 0},
+    "non_local_opt": {"a": "0.", "alpha": 0.0, "c": "0.", "gamma": "0.", "lamda": "0.", "beta_1": "0.",
+                      "beta_2": "0.", "maxfev": 0, "global_iters": 1000, "method": "scipy_each_step",
+                      "optim_alg": "COBYLA"},
+}
+
+
+def write_chain_dataset(root, n, model="heisenberg", seed=20, eigvals=None, **kw):
+    """mol_data/<model>_<n>q.npz + init_state_circ/init_<model>_<n>q_TNbond2.qasm for the chain models the
+    reference names without geometry (environment_qulacs_TN_notin_agent.py:78,122).  The Hamiltonian is the
+    reference's own formula at any n (dmrg-to-qc/heisenberg_model.py:22-72; the shipped TFIM fixture) with a
+    Lanczos ground energy where the dense spectrum cannot exist; the init circuit is a synthetic chi = 2
+    stand-in (the reference's DMRG -> MPS -> circuit chain needs quimb; its fit block is
+    ``tensorrl_qas_amd.dmrg_to_qc``)."""
+    import copy
+    os.makedirs(os.path.join(root, "mol_data"), exist_ok=True)
+    os.makedirs(os.path.join(root, "init_state_circ"), exist_ok=True)
+    if model == "heisenberg":
+        ham, _ = _ham.heisenberg(n)
+    else:
+        ham, _ = _ham.tfim(n, **kw)
+        model = "tfim_j1_h0.05" if (kw.get("j", 1.0), kw.get("h")) == (1.0, 0.05) else ham.label.rsplit("_", 1)[0]
+    _ham.write_npz(os.path.join(root, "mol_data", f"{model}_{n}q.npz"), ham, eigvals=eigvals)
+    with open(os.path.join(root, "init_state_circ", f"init_{model}_{n}q_TNbond2.qasm"), "w") as f:
+        f.write(init_circuit_qasm(n, seed))
+    conf = copy.deepcopy(HEIS_FIXED_CONFIG_TEMPLATE)
+    conf["env"].update(num_qubits=n, num_layers=27 + 40, data_root=root)
+    conf["problem"]["ham_type"] = model
+    return conf

