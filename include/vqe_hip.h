@@ -75,6 +75,14 @@ int vqe_set_init_state(vqe_t* h, const double* amps_re_im /* 2 * 2^n, or NULL */
  * built at environment_qulacs_TN_notin_agent.py:126-131,162) by its Pauli-sum form */
 int vqe_set_hamiltonian_pauli(vqe_t* h, int n_terms, const uint64_t* xmask,
                               const uint64_t* zmask, const double* coeff);
+/* The same operator as the reference hands it to get_exp_val: a dense 2^n x 2^n complex matrix in the
+ * simulator's little-endian basis, row-major, (re, im) interleaved - i.e. the product of
+ * Operator(H).reverse_qargs().to_matrix() (environment_qulacs_TN_notin_agent.py:162) on the fixed path, the raw
+ * file matrix on the trainable path.  Decomposed into Pauli terms on the host (one Walsh-Hadamard transform
+ * per X mask; coefficients below tol * max|H_ij| are dropped; n <= 13).  vqe_hamiltonian_terms reports what
+ * was found. */
+int vqe_set_hamiltonian_dense(vqe_t* h, const double* op_re_im /* 2 * 4^n */, double tol);
+int vqe_hamiltonian_terms(vqe_t* h, int32_t* n_terms, int32_t* n_xgroups);
 /* Evaluate only the X-mask groups owned by `rank` of `world` (Pauli-term sharding; the
  * caller sums the partial energies of all ranks, e.g. one RCCL all-reduce). */
 int vqe_set_term_shard(vqe_t* h, int rank, int world);

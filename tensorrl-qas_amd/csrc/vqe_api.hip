@@ -5,6 +5,7 @@
 #include "vqe_stream.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -819,6 +820,55 @@ int vqe_set_hamiltonian_pauli(vqe_t* h, int n_terms, const uint64_t* xmask, cons
   }
   h->ham_set = true;
   return build_hamiltonian(h);
+}
+
+int vqe_set_hamiltonian_dense(vqe_t* h, const double* op_re_im, double tol) {
+  if (!h) return VQE_EINVAL;
+  if (!op_re_im || !(tol >= 0.0)) return fail(h, VQE_EINVAL, "bad Hamiltonian arguments");
+  if (h->n > 13) return fail(h, VQE_EINVAL, "a dense 2^n x 2^n operator is accepted up to 13 qubits (17 TB at n = 20): use vqe_set_hamiltonian_pauli");
+  // H = sum_{x,z} c(x,z) P(x,z), P|i> = i^{#Y} (-1)^{popc(i & z)} |i ^ x>  =>  for fixed x the coefficients are the
+  // Walsh-Hadamard transform over i of the generalised diagonal H[i ^ x, i], divided by 2^n i^{#Y}
+  const size_t dim = (size_t)1 << h->n;
+  std::vector<uint64_t> xs, zs;
+  std::vector<double> cs;
+  std::vector<double> re(dim), im(dim);
+  double scale = 0.0;
+  for (size_t k = 0; k < 2 * dim * dim; ++k) scale = std::max(scale, std::fabs(op_re_im[k]));
+  const double cut = tol * (scale > 0 ? scale : 1.0);
+  for (size_t x = 0; x < dim; ++x) {
+    bool any = false;
+    for (size_t i = 0; i < dim; ++i) {
+      const double* e = op_re_im + 2 * ((i ^ x) * dim + i);
+      re[i] = e[0]; im[i] = e[1];
+      any = any || e[0] != 0.0 || e[1] != 0.0;
+    }
+    if (!any) continue;
+    for (size_t step = 1; step < dim; step <<= 1)
+      for (size_t i = 0; i < dim; i += 2 * step)
+        for (size_t j = i; j < i + step; ++j) {
+          const double ar = re[j], ai = im[j], br = re[j + step], bi = im[j + step];
+          re[j] = ar + br; im[j] = ai + bi; re[j + step] = ar - br; im[j + step] = ai - bi;
+        }
+    for (size_t z = 0; z < dim; ++z) {
+      double cr = re[z] / (double)dim, ci = im[z] / (double)dim;
+      const int ny = __builtin_popcountll(x & z) & 3;      // divide by i^ny
+      double vr, vi;
+      if (ny == 0) { vr = cr; vi = ci; } else if (ny == 1) { vr = ci; vi = -cr; } else if (ny == 2) { vr = -cr; vi = -ci; } else { vr = -ci; vi = cr; }
+      if (std::fabs(vr) <= cut && std::fabs(vi) <= cut) continue;
+      if (std::fabs(vi) > 1e-9 * (scale > 0 ? scale : 1.0) && std::fabs(vi) > cut)
+        return fail(h, VQE_EINVAL, "operator is not Hermitian (complex Pauli coefficient)");
+      xs.push_back(x); zs.push_back(z); cs.push_back(vr);
+    }
+  }
+  return vqe_set_hamiltonian_pauli(h, (int)cs.size(), xs.data(), zs.data(), cs.data());
+}
+
+int vqe_hamiltonian_terms(vqe_t* h, int32_t* n_terms, int32_t* n_xgroups) {
+  if (!h || !n_terms || !n_xgroups) return VQE_EINVAL;
+  if (!h->ham_set) return fail(h, VQE_ESTATE, "no Hamiltonian set");
+  *n_terms = (int32_t)h->hx.size();
+  *n_xgroups = (int32_t)h->gx_all.size();
+  return VQE_OK;
 }
 
 int vqe_set_term_shard(vqe_t* h, int rank, int world) {

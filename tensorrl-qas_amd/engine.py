@@ -117,6 +117,18 @@ class VQEEngine:
             raise ValueError("xmask, zmask, coeff differ in length")
         self._chk(self._lib.vqe_set_hamiltonian_pauli(self._h, int(x.size), _p(x, c_u64p), _p(z, c_u64p), _p(c, c_f64p)))
 
+    def set_hamiltonian_dense(self, op, tol: float = 1e-13):
+        """Dense operator in the simulator's little-endian basis (what the reference passes to
+        get_exp_val); decomposed into Pauli terms by the library.  Returns (n_terms, n_xgroups)."""
+        a = np.ascontiguousarray(op, dtype=np.complex128)
+        dim = 1 << self.n_qubits
+        if a.shape != (dim, dim):
+            raise ValueError("operator has the wrong shape")
+        self._chk(self._lib.vqe_set_hamiltonian_dense(self._h, a.view(np.float64).ctypes.data_as(c_f64p), float(tol)))
+        nt, ng = C.c_int32(), C.c_int32()
+        self._chk(self._lib.vqe_hamiltonian_terms(self._h, C.byref(nt), C.byref(ng)))
+        return nt.value, ng.value
+
     def set_term_shard(self, rank: int, world: int):
         self._chk(self._lib.vqe_set_term_shard(self._h, int(rank), int(world)))
 

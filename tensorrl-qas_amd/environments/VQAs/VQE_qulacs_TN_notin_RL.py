@@ -14,26 +14,24 @@ from ... import circuits as _circ
 from ... import hamiltonian as _ham
 from ...engine import VQEEngine
 
-_engines = {}
+_live = None      # (n_qubits, observable, TN_state, device_id, engine): ONE live engine, as the reference keeps one circuit
 
 
 def _engine_for(n_qubits, observable, TN_state, device_id=0):
-    key = (n_qubits, id(observable), None if TN_state is None else id(TN_state), device_id)
-    eng = _engines.get(key)
-    if eng is None:
-        if not isinstance(observable, _ham.PauliHamiltonian):
-            op = np.asarray(observable)
-            r = _ham._bitrev
-            # dense little-endian matrix: index bit b <-> simulator qubit b
-            xs, zs, cs = _ham.pauli_from_dense(op, reverse_qargs=False)
-            observable_p = _ham.PauliHamiltonian(n_qubits, xs, zs, cs)
-        else:
-            observable_p = observable
-        eng = VQEEngine(n_qubits, device_id)
-        eng.set_hamiltonian(observable_p.xmask, observable_p.zmask, observable_p.coeff)
-        eng.set_init_state(TN_state)
-        _engines.clear()          # keep one live engine, as the reference keeps one circuit
-        _engines[key] = eng
+    """Engine configured for (observable, TN_state).  The cache entry holds REFERENCES to the two objects
+    and is matched by identity, so an id() recycled after garbage collection can never alias a stale
+    Hamiltonian."""
+    global _live
+    if (_live is not None and _live[0] == n_qubits and _live[1] is observable and _live[2] is TN_state
+            and _live[3] == device_id):
+        return _live[4]
+    eng = VQEEngine(n_qubits, device_id)
+    if isinstance(observable, _ham.PauliHamiltonian):
+        eng.set_hamiltonian(observable.xmask, observable.zmask, observable.coeff)
+    else:      # dense matrix, little-endian simulator basis: decomposed by the library (vqe_set_hamiltonian_dense)
+        eng.set_hamiltonian_dense(np.asarray(observable))
+    eng.set_init_state(TN_state)
+    _live = (n_qubits, observable, TN_state, device_id, eng)
     return eng
 
 

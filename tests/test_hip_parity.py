@@ -691,3 +691,42 @@ def test_noisy_minimize_is_a_pure_function_of_the_seed(tq):
     assert not np.array_equal(outs[0][1], outs[2][1])
     # streams of one batch see different noise realisations
     assert len(set(outs[0][1].tolist())) == 3
+
+
+def test_dense_hamiltonian_entry_point(tq):
+    """vqe_set_hamiltonian_dense: the operator as the reference hands it to get_exp_val (dense, little-endian
+    simulator basis; environment_qulacs_TN_notin_agent.py:162) is decomposed by the library - term and group
+    counts of the shipped H2O-8q Hamiltonian are recovered and energies equal the literal dense expression."""
+    d = load_case("H2O_8q")
+    n = d["n"]
+    dense = vo.pauli_dense(d["paulis"], d["weights"], n)          # == Operator(H).reverse_qargs().to_matrix() (tests/test_oracle.py)
+    psi0 = oracle_init_state(d)
+    eng = tq.VQEEngine(n)
+    eng.set_init_state(psi0)
+    nt, ng = eng.set_hamiltonian_dense(dense)
+    xs, _ = vo.pauli_masks(d["paulis"], n)
+    assert nt == len(d["paulis"]) and ng == len(set(xs.tolist()))
+    rng = np.random.default_rng(8)
+    kind, q0, q1, pidx, th = random_gates(n, 25, rng)
+    eng.set_circuit(tq.Circuit(kind, q0, q1, pidx, th.size))
+    assert abs(eng.energy(th) - vo.energy_dense(vo.run_circuit(psi0, kind, q0, q1, pidx, th), dense)) < E_TOL
+    eng.set_circuit(tq.Circuit.empty())
+    assert abs(eng.energy(np.zeros(0)) - known_answers()["H2O_8q"]["e_init_fixed"]) < E_TOL
+    # complex Hermitian operator (odd number of Y factors) and a non-Hermitian one
+    m = 4
+    ham = random_hamiltonian(m, 40, rng, real=False)
+    dn = np.zeros((16, 16), complex)
+    idx = np.arange(16)
+    for x, z, w in zip(*ham):
+        x, z = int(x), int(z)
+        dn[idx ^ x, idx] += w * (1.0 - 2.0 * vo._parity(idx & z)) * (1j ** bin(x & z).count("1"))
+    e4 = tq.VQEEngine(m)
+    s4 = random_state(m, rng)
+    e4.set_init_state(s4)
+    e4.set_hamiltonian_dense(dn)
+    e4.set_circuit(tq.Circuit.empty())
+    assert abs(e4.energy(np.zeros(0)) - vo.energy_dense(s4, dn)) < E_TOL
+    with pytest.raises(tq.VQEError, match="Hermitian"):
+        e4.set_hamiltonian_dense(dn + 0.3j * np.eye(16))
+    with pytest.raises(ValueError):
+        tq.VQEEngine(14).set_hamiltonian_dense(np.zeros((1, 1)))    # wrong shape is caught by the wrapper
