@@ -341,15 +341,27 @@ def heis20_aux(tq, torch, dist, rank, world, dev, steps):
     g_rot = float(np.count_nonzero(batch["kind"])) / B
     bytes_per_eval = (1 << n) * 16 * (2 * g_rot + 20)
     evals_s = B * steps / float(t[0].item())
+    roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "note": "no profiles/pmc_heis20.json for this workload (tools/pmc_heis20.sh)"}
+    tfile = os.path.join(ROOT, "profiles", "pmc_heis20.json")
+    if os.path.exists(tfile):      # HBM bytes of one batched evaluation from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        tr = json.load(open(tfile))
+        if tr.get("workload") == "heisenberg_20q_77terms_G32_B256_sharded":
+            per_batch = tr["hbm_bytes_per_batch"]
+            gbs = per_batch * (evals_s / B) / 1e9
+            roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "traffic": per_batch, "traffic_source": tr["source"],
+                    "note": "measured HBM bytes of one batch of 256 evaluations (all k_t_* / k_s_* launches, one GPU) x batches/s of "
+                            "this run; at N > 1 every rank moves the circuit part again, so this is the per-GPU figure at N = 1"}
+    roof["algorithmic"] = {"bytes_per_evaluation": bytes_per_eval, "mean_rotations": g_rot,
+                           "GBs_if_every_gate_and_group_streamed": bytes_per_eval * evals_s / 1e9,
+                           "note": "SURVEY 8d figure 2^n*16*(2 G_rot + T_x): informational - the LDS-tiled kernels apply several "
+                                   "ops / groups per pass over the state"}
     return {"workload": "heisenberg_20q_77terms_G32_B256_sharded", "evals_per_s": evals_s,
-            "roofline": {"bound": "hbm", "achieved": bytes_per_eval * evals_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bytes_per_eval * evals_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_eval": bytes_per_eval, "mean_rotations": g_rot,
-                         "note": "all ranks together; four ops share one read-modify-write sweep of the state (DESIGN 4.3), "
-                                 "so fewer bytes move than the per-gate figure counts: frac may exceed 1"},
+            "roofline": roof,
             "reduction_ms_per_batch": float(t[1].item()) / steps * 1e3,
             "reduction_evals_per_s": B * steps / float(t[1].item()),
-            "x_groups_total": 20, "sharding": "amplitude slices of the term sum, 1 all-reduce", "energy_checksum": float(e.sum().item()), "scaling": "strong"}
+            "x_groups_total": 20, "sharding": "amplitude slices (tiles) of the term sum, 1 all-reduce", "energy_checksum": float(e.sum().item()), "scaling": "strong"}
 
 
 def self_launch(args):
@@ -415,9 +427,11 @@ def pmc_roofline(workload, k_ms, evals_per_launch):
     if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
         # LDS-array cycles summed over the CUs / (CUs x kernel cycles): utilisation of the LDS pipes
         cus = pm.get("cu_count", 256)
+        xcds = pm.get("xcd_count", 8)      # GRBM_GUI_ACTIVE is summed over the XCDs, SQ_* over all CUs
         out["lds"] = {"array_cycles_per_launch": c["SQ_LDS_IDX_ACTIVE"], "bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"),
-                      "frac": c["SQ_LDS_IDX_ACTIVE"] / (cus * c["GRBM_GUI_ACTIVE"]),
-                      "note": "SQ_LDS_IDX_ACTIVE / (CUs x GRBM_GUI_ACTIVE): share of cycles the LDS arrays are busy"}
+                      "frac": c["SQ_LDS_IDX_ACTIVE"] / (cus * c["GRBM_GUI_ACTIVE"] / xcds),
+                      "note": "SQ_LDS_IDX_ACTIVE / (CUs x kernel cycles): share of cycles the LDS arrays are busy "
+                              "(kernel cycles = GRBM_GUI_ACTIVE / XCDs)"}
     return out
 
 
@@ -452,7 +466,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the G in {8,32,64,110} auxiliary launches")
     ap.add_argument("--no-episode", action="store_true", help="skip the LIH12q fixed config through VecCircuitEnv")
     ap.add_argument("--episode", action="store_true", help="(default at N = 1; kept for older command lines)")
-    ap.add_argument("--episode-envs", type=int, default=2048)
+    ap.add_argument("--episode-envs", type=int, default=4096)
     ap.add_argument("--episode-steps", type=int, default=110)
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' "

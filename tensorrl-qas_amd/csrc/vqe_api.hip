@@ -94,6 +94,7 @@ struct vqe_handle {
   bool trace_on = false;
   int trace_maxfun = 0, trace_stride = 0, trace_batch = 0;
   StreamWork sw;  // streaming-path work buffers
+  uint64_t gen = 0;   // bumped whenever a resident batch / Hamiltonian shard / noise setting changes (plans of vqe_tile.h)
 };
 
 #ifdef VQE_STAMPS
@@ -230,6 +231,7 @@ IndexMap choose_index_map(int n, int lt, const std::vector<uint32_t>& xs) {
 // Build (or rebuild after re-sharding) the device Hamiltonian.
 int build_hamiltonian(vqe_t* h) {
   const int n = h->n;
+  ++h->gen;
   const std::vector<int> owner = assign_groups(h->gx_all, h->group_terms, h->lds_path, h->shard_world);
   std::vector<int> mine;
   for (size_t g = 0; g < owner.size(); ++g) if (owner[g] == h->shard_rank) mine.push_back((int)g);
@@ -511,6 +513,7 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   h->h_gate_begin = gbeg;
   h->h_theta.assign(theta0, theta0 + total_params);
   h->has_new_gate = false;
+  ++h->gen;
   return VQE_OK;
 }
 
@@ -551,7 +554,7 @@ int stream_cobyla(vqe_t* h, BatchArgs& A, const std::vector<int64_t>& pbeg, cons
     if (!x.empty())
       HIP_TRY(h, hipMemcpyAsync(h->d_x.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
     A.theta = h->d_x.p;  // trial points live in the output buffer; x0 stays untouched
-    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base + (++it), true, h->err);
+    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base + (++it), true, h->err, true, h->gen);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(f.data(), h->d_f.p, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -568,12 +571,12 @@ int stream_run(vqe_t* h, int which, BatchArgs& A) {
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
   int rc = 0;
   if (which == 0) {
-    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base, true, h->err);
+    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base, true, h->err, true, h->gen);
   } else if (which == 4) {   // Pauli-term reduction only, on the states of the previous run
     if (h->sw.states_cap < ((size_t)h->batch << h->n)) return fail(h, VQE_ESTATE, "no states: run the energy first");
-    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base, true, h->err, false);
+    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base, true, h->err, false, h->gen);
   } else if (which == 2) {
-    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base, false, h->err);
+    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base, false, h->err, true, h->gen);
     if (!rc) {
       const size_t dim = (size_t)1 << h->n;
       hipLaunchKernelGGL(k_s_state_out, dim3((unsigned)(dim / kThreads)), dim3(kThreads), 0, h->stream, A,
@@ -631,6 +634,7 @@ int stream_run(vqe_t* h, int which, BatchArgs& A) {
       pcnt2[b] = (int32_t)((int64_t)x0.size() - pbeg2[b]);
     }
     int rc2;
+    ++h->gen;      // d_gates2 changes content: plans made for it are stale
     if ((rc2 = upload(h, h->d_gates2, g2.data(), g2.size()))) return rc2;
     if ((rc2 = upload(h, h->d_gate_begin2, gbeg2.data(), gbeg2.size()))) return rc2;
     if ((rc2 = upload(h, h->d_gate_count2, gcnt2.data(), gcnt2.size()))) return rc2;
@@ -659,7 +663,7 @@ int stream_run(vqe_t* h, int which, BatchArgs& A) {
     HIP_TRY(h, hipMemcpyAsync(h->d_nfev.p, nfev.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));      // host vectors stay alive until the copies are done
     A.theta = h->d_x.p;
-    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base + (uint64_t)A.maxfun + 1, true, h->err);
+    rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base + (uint64_t)A.maxfun + 1, true, h->err, true, h->gen);
   }
   if (rc) return rc;
   HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
@@ -886,9 +890,10 @@ int vqe_set_amplitude_shard(vqe_t* h, int rank, int world) {
   if (h->lds_path && world > 1)
     return fail(h, VQE_ESTATE, "amplitude sharding of the energy sweep exists on the streaming path (n >= 14); use vqe_set_term_shard");
   const size_t blocks = ((size_t)1 << h->n) >> kTileBits;      // tiles of the energy sweep (vqe_tile.h)
-  if (!h->lds_path && (blocks % (size_t)world) != 0) return fail(h, VQE_EINVAL, "world must divide the number of sweep tiles (2^(n-12))");
+  if (!h->lds_path && (blocks % (size_t)world) != 0) return fail(h, VQE_EINVAL, "world must divide the number of sweep tiles of the energy reduction");
   h->amp_rank = rank;
   h->amp_world = world;
+  ++h->gen;
   return VQE_OK;
 }
 
@@ -896,6 +901,7 @@ int vqe_set_noise(vqe_t* h, double p1, double p2, uint64_t seed) {
   if (!h) return VQE_EINVAL;
   if (!(p1 >= 0.0 && p1 <= 1.0 && p2 >= 0.0 && p2 <= 1.0)) return fail(h, VQE_EINVAL, "noise probability outside [0,1]");
   h->noise = NoiseCfg{p1, p2, seed, 0ull, h->noise.shot_sigma};
+  ++h->gen;
   return VQE_OK;
 }
 

@@ -36,6 +36,9 @@ struct StreamWork {
   void* epasses = nullptr;    size_t epasses_cap = 0;  // TilePass [batch][kMaxEnergyPasses]
   int32_t* eorder = nullptr;  size_t eorder_cap = 0;   // [batch][n_groups] group ids pass by pass, then [batch][n_groups] pass of a group
   uint32_t* gcx = nullptr;    size_t gcx_cap = 0;      // [batch][n_groups]
+  // plans depend on the gate lists, the Hamiltonian shard and (through the drawn Paulis) on the noise, not on theta:
+  // a noiseless re-evaluation of the same resident batch (COBYLA iterations, repeated runs) keeps them
+  const void* plan_src = nullptr; uint64_t plan_gen = ~0ull; bool plan_ops_ok = false, plan_energy_ok = false;
   void* trec = nullptr;       size_t trec_cap = 0;     // TermRec [batch][n_terms]
   int32_t* grec = nullptr;    size_t grec_cap = 0;     // [batch][n_groups]
   ~StreamWork() {
@@ -402,12 +405,17 @@ namespace vqe {
 inline bool stream_tiled(int n_groups, int n_terms) {
   static const bool env_on = [] { const char* e = getenv("VQE_STREAM_TILED"); return !(e && e[0] == '0'); }();
   return env_on && (n_groups + kTileFree - 1) / kTileFree + 1 <= kMaxEnergyPasses &&
-         sizeof(double2) * kTileAmps + sizeof(TermLds) * (size_t)(n_terms > 0 ? n_terms : 1) <= 160 * 1024;
+         sizeof(double2) * kTileAmps + sizeof(TermLds) * (size_t)(n_terms > 0 ? n_terms : 1) <= 64 * 1024;
 }
 
 inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipStream_t st,
-                           uint64_t eval_id, bool want_energy, std::string& err, bool want_circuit = true) {
+                           uint64_t eval_id, bool want_energy, std::string& err, bool want_circuit = true,
+                           uint64_t generation = 0) {
   const size_t dim = (size_t)1 << A.n;
+  const bool noisy = A.noise.p1 > 0.0 || A.noise.p2 > 0.0;
+  if (sw.plan_src != (const void*)A.gates || sw.plan_gen != generation || noisy) sw.plan_ops_ok = sw.plan_energy_ok = false;
+  sw.plan_src = (const void*)A.gates;
+  sw.plan_gen = generation;
   const int B = A.batch;
   SW_TRY(sw_reserve(sw.states, sw.states_cap, (size_t)B * dim));
   SW_TRY(sw_reserve(sw.ops, sw.ops_cap, (size_t)B * A.max_ops));
@@ -443,21 +451,28 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
     const int tiles_rank = tiles / world;
     SW_TRY(sw_reserve(sw.partial, sw.partial_cap, (size_t)B * e_pass * tiles_rank));
     if (want_circuit) {
-      hipLaunchKernelGGL(k_s_compile, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.masks, sw.meta, eval_id);
       hipLaunchKernelGGL(k_s_sincos, dim3((A.max_params + 63) / 64, B), dim3(64), 0, st, A, sw.cs);
-      hipLaunchKernelGGL(k_t_plan_ops, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.meta, (TilePass*)sw.passes,
-                         (OpCoord*)sw.opc, sw.npass, max_pass);
+      if (!sw.plan_ops_ok) {
+        hipLaunchKernelGGL(k_s_compile, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.masks, sw.meta, eval_id);
+        hipLaunchKernelGGL(k_t_plan_ops, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.meta, (TilePass*)sw.passes,
+                           (OpCoord*)sw.opc, sw.npass, max_pass);
+        sw.plan_ops_ok = !noisy;
+        sw.plan_energy_ok = false;       // the Pauli masks follow the layout the circuit leaves
+      }
       for (int p = 0; p < max_pass; ++p)
         hipLaunchKernelGGL(k_t_ops, dim3((unsigned)tiles, B), dim3(kThreads), 0, st, A, sw.states, sw.ops,
                            (const OpCoord*)sw.opc, sw.cs, (const TilePass*)sw.passes, sw.npass, p, max_pass);
     }
     if (want_energy) {
-      const int m = std::max(nt, ng);
-      hipLaunchKernelGGL(k_s_terms, dim3((m + 63) / 64, B), dim3(64), 0, st, A, sw.masks, sw.meta, n_terms,
-                         sw.gxp, sw.tzp, sw.tsg);
-      hipLaunchKernelGGL(k_t_plan_energy, dim3((B + 63) / 64), dim3(64), 0, st, A, n_terms, sw.gxp, sw.tzp, sw.tsg,
-                         (TilePass*)sw.epasses, sw.npass + B, sw.eorder, sw.gcx, sw.grec, (TermRec*)sw.trec,
-                         sw.eorder + (size_t)B * ng);
+      if (!sw.plan_energy_ok) {
+        const int m = std::max(nt, ng);
+        hipLaunchKernelGGL(k_s_terms, dim3((m + 63) / 64, B), dim3(64), 0, st, A, sw.masks, sw.meta, n_terms,
+                           sw.gxp, sw.tzp, sw.tsg);
+        hipLaunchKernelGGL(k_t_plan_energy, dim3((B + 63) / 64), dim3(64), 0, st, A, n_terms, sw.gxp, sw.tzp, sw.tsg,
+                           (TilePass*)sw.epasses, sw.npass + B, sw.eorder, sw.gcx, sw.grec, (TermRec*)sw.trec,
+                           sw.eorder + (size_t)B * ng);
+        sw.plan_energy_ok = !noisy && sw.plan_ops_ok;
+      }
       const size_t elds = sizeof(double2) * kTileAmps + sizeof(TermLds) * (size_t)nt;
       SW_TRY(hipFuncSetAttribute((const void*)k_t_energy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
       hipLaunchKernelGGL(k_t_energy, dim3((unsigned)tiles_rank, B, e_pass), dim3(kThreads), elds, st, A, sw.states, n_terms,

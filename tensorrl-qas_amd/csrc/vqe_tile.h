@@ -2,11 +2,12 @@
 //
 // One gate sweep over a 20-qubit state moves 32 MiB through HBM; a circuit of ~16 rotations and a
 // Hamiltonian of ~20 X-mask groups would move it ~25 times if every op / group streamed the vector.
-// Instead a workgroup stages a TILE of 2^12 amplitudes (64 KiB of LDS, two workgroups per CU) and does
-// everything that closes inside it before the tile goes back:
-//   * a tile is a coset p0 ^ V of a 12-dimensional subspace V of GF(2)^n that contains the unit vectors
+// Instead a workgroup stages a TILE of 2^11 amplitudes (32 KiB of LDS, four workgroups per CU: measured
+// 31.5 k evaluations/s on the 20-qubit bench workload against 25.9 k with 64 KiB tiles and 28.4 k with
+// 16 KiB ones - occupancy against passes) and does everything that closes inside it before the tile goes back:
+//   * a tile is a coset p0 ^ V of an 11-dimensional subspace V of GF(2)^n that contains the unit vectors
 //     e_0..e_3 (so the tile is made of aligned 256-byte runs: coalesced loads and stores) plus up to
-//     eight independent pair masks - the physical partner masks A^-1 e_q of the rotations (vqe_device.h:
+//     seven independent pair masks - the physical partner masks A^-1 e_q of the rotations (vqe_device.h:
 //     CNOTs never move data), or the physical X masks of Pauli groups; masks that DEPEND on the basis ride
 //     along for free;
 //   * a planner thread per stream cuts the op list into passes (maximal runs of ops whose masks fit one
@@ -14,8 +15,8 @@
 //     coordinates of a mask are just its bits at the pivot positions, and the sign selector parity(p & z)
 //     of a rotation / Pauli term splits into parity(p0 & z) (per tile, scalar) ^ parity(t & cz) with
 //     cz_i = parity(basis_i & z);
-//   * inside a tile four ops at a time are applied from registers (the coset trick of k_s_opk, in tile
-//     coordinates), so LDS sees one read + one write of the tile per four ops;
+//   * inside a tile three ops at a time are applied from registers (the coset trick of k_s_opk, in tile
+//     coordinates: 256 threads x 8 amplitudes), so LDS sees one read + one write of the tile per three ops;
 //   * the first pass of a stream reads the shared initial state instead of its own buffer (no separate
 //     initialisation sweep).
 // Every floating-point update is the per-element form of s_apply_k (vqe_stream.h), so states and
@@ -25,7 +26,10 @@
 
 namespace vqe {
 
-constexpr int kTileBits = 12;
+#ifndef VQE_TILE_BITS
+#define VQE_TILE_BITS 11
+#endif
+constexpr int kTileBits = VQE_TILE_BITS;
 constexpr int kTileLow = 4;
 constexpr int kTileAmps = 1 << kTileBits;
 constexpr int kTileFree = kTileBits - kTileLow;   // independent masks a pass can take
@@ -228,7 +232,7 @@ __device__ __forceinline__ uint32_t tile_lane_offset(const uint32_t (&basis)[kTi
 __device__ __forceinline__ uint32_t tile_k_offset(const uint32_t (&basis)[kTileBits], int k) {
   uint32_t x = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) if ((k >> i) & 1) x ^= basis[kTileLow + 4 + i];
+  for (int i = 0; i < kTileBits - kTileLow - 4; ++i) if ((k >> i) & 1) x ^= basis[kTileLow + 4 + i];
   return x;
 }
 
@@ -236,7 +240,7 @@ __device__ __forceinline__ uint32_t tile_k_offset(const uint32_t (&basis)[kTileB
 __global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states, const Op* ops, const OpCoord* opc,
                                                     const double2* cs, const TilePass* passes, const int32_t* npass,
                                                     int pass, int max_pass) {
-  constexpr int K = 4, E = 1 << K;
+  constexpr int K = kTileBits - 8, E = 1 << K;      // 256 threads x 2^K amplitudes = one tile
   __shared__ double2 tile[kTileAmps];
   const int b = blockIdx.y;
   if (pass >= npass[b]) return;
