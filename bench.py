@@ -424,6 +424,15 @@ def pmc_roofline(workload, k_ms, evals_per_launch):
            "hbm": {"achieved": hbm / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / sec / 1e9 / HBM_PEAK_GBS},
            "fp64_share_of_wave_instructions": (c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"])
            / max(1.0, c.get("SQ_INSTS_ALL", 0.0)) if c.get("SQ_INSTS_ALL") else None}
+    if c.get("SQ_INSTS_ALL") and c.get("SQ_WAVE_CYCLES"):
+        waves = 4.0 * pm["evaluations_per_launch"]      # 4 wavefronts per workgroup, one workgroup per evaluation stream
+        out["issue"] = {"wave_instructions_per_evaluation": c["SQ_INSTS_ALL"] / waves,
+                        "of_which_fp64_valu": (c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]) / waves,
+                        "wave_cycles_instruction_active": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                        "wave_cycles_waiting_on_counter": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                        "wave_cycles_waiting_for_issue": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                        "note": "SQ_* sums of the same counter file (quad-cycles of all waves): what bounds the kernel is "
+                                "instruction issue at 2 waves per SIMD (LDS-limited occupancy), DESIGN.md 4.1"}
     if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
         # LDS-array cycles summed over the CUs / (CUs x kernel cycles): utilisation of the LDS pipes
         cus = pm.get("cu_count", 256)
@@ -614,11 +623,6 @@ def main():
             out["gate_sweep"] = sweep
         if episode is not None:
             out["episode"] = episode
-        ifile = os.path.join(ROOT, "profiles", "issue_stats.json")
-        if os.path.exists(ifile):      # what actually bounds the LDS-resident kernel (PMC evidence)
-            st = json.load(open(ifile))
-            if st.get("workload") == out["config"]["workload"]:
-                out["roofline"]["issue"] = {k: st[k] for k in st if k not in ("workload", "kernel")}
         if heis is not None:
             out["heis20"] = heis
         if not args.no_mps2qc:
