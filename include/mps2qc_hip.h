@@ -69,6 +69,22 @@ int mps2qc_fit_brickwork(int device_id, int n_qubits, int n_gates, const int32_t
                          double* best_val, int32_t* n_iter,
                          double* last_envs, double* last_overlap, float* kernel_ms);
 
+/* The same fit with the state vectors in HBM instead of LDS: registers of 2 .. MPS2QC_STREAM_MAX_QUBITS qubits
+ * (what the reference reaches beyond a dozen qubits only as a tensor-network contraction, mps2qc.py:242-339; a
+ * dense 2^n target is 16 MiB at 20 qubits).  Same arguments, same optimiser and bookkeeping semantics and the
+ * same outputs as mps2qc_fit_brickwork (no use_mfma: the 4x4 environments are reduced by a fused backward
+ * sweep per gate); the optimiser update runs on the host, so an active fit that has stopped does not hold the
+ * others back.  total_ms: duration of the whole loop. */
+#define MPS2QC_STREAM_MAX_QUBITS 26
+int mps2qc_fit_brickwork_stream(int device_id, int n_qubits, int n_gates, const int32_t* sites,
+                                int batch, const double* target, int target_shared,
+                                const double* init_gates,
+                                double lr, double beta1, double beta2, double eps, int jit_frozen,
+                                int max_iter, double tol, double param_tol,
+                                double* opt_gates, double* final_gates, double* loss_history,
+                                double* best_val, int32_t* n_iter,
+                                double* last_envs, double* last_overlap, float* total_ms);
+
 /* Message of the last failure on the calling thread ("" if none). */
 const char* mps2qc_last_error(void);
 

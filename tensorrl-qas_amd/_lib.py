@@ -106,6 +106,11 @@ MPS2QC_SIGNATURES = {
                                        C.c_int, C.c_double, C.c_double, C.c_int,
                                        c_f64p, c_f64p, c_f64p, c_f64p, c_i32p, c_f64p, c_f64p,
                                        C.POINTER(C.c_float)]),
+    "mps2qc_fit_brickwork_stream": (C.c_int, [C.c_int, C.c_int, C.c_int, c_i32p, C.c_int, c_f64p, C.c_int, c_f64p,
+                                              C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                              C.c_int, C.c_double, C.c_double,
+                                              c_f64p, c_f64p, c_f64p, c_f64p, c_i32p, c_f64p, c_f64p,
+                                              C.POINTER(C.c_float)]),
     "mps2qc_last_error": (C.c_char_p, []),
 }
 

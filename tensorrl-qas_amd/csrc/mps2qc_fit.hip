@@ -935,3 +935,353 @@ done:
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// HBM-streaming variant for registers beyond MPS2QC_MAX_QUBITS (13 .. 26 qubits): the states no longer
+// fit LDS, but a dense 2^n target is small by MI355X standards (16 MiB at 20 qubits; 288 GB of HBM hold
+// the two work vectors of a fit up to ~33 qubits) - this is the dense-target answer to the reference's
+// "MPS form" contraction (dmrg-to-qc/mps2qc.py:242-339) at sizes where quimb contracts a tensor network.
+// Same optimisation loop as k_fit, cut at the kernel boundary:
+//   forward   G coalesced sweeps psi <- U_k psi             (k_sf_apply: a thread owns one 4-vector)
+//   overlap   o = <t|psi>                                    (k_sf_dot + fixed-order second stage)
+//   backward  per gate ONE fused sweep: psi <- U_k^H psi, E_k += conj(phi_a) psi_b, phi <- U_k^H phi
+//             (k_sf_back: per-block partials of the 16 complex entries, fixed-order second stage)
+//   update    StiefelAdam.update + the bookkeeping of minimize() on the HOST (16 x G complex numbers
+//             per fit and step; one device round trip per step against ~1 ms of sweeps at 20 qubits)
+namespace {
+
+constexpr int kSfThreads = 256;
+
+struct SfGate { double2 m[16]; };      // one gate (or its adjoint), passed by value: scalar registers
+
+__global__ void __launch_bounds__(kSfThreads) k_sf_zero_state(double2* psi, size_t dim) {
+  const size_t i = (size_t)blockIdx.x * kSfThreads + threadIdx.x;
+  double2* p = psi + (size_t)blockIdx.y * dim;
+  if (i < dim) p[i] = make_double2(i == 0 ? 1.0 : 0.0, 0.0);
+}
+
+__global__ void __launch_bounds__(kSfThreads) k_sf_copy(double2* dst, const double2* src, size_t dim, int src_shared) {
+  const size_t i = (size_t)blockIdx.x * kSfThreads + threadIdx.x;
+  if (i < dim) dst[(size_t)blockIdx.y * dim + i] = src[(src_shared ? 0 : (size_t)blockIdx.y * dim) + i];
+}
+
+// st <- M st on the qubit pair with low bit `lo`; gates: [B][G][16], gate k of fit blockIdx.y (adjoint if dagger)
+__global__ void __launch_bounds__(kSfThreads) k_sf_apply(double2* states, size_t dim, const double2* gates, int G, int k,
+                                                         int lo, int dagger) {
+  const size_t r = (size_t)blockIdx.x * kSfThreads + threadIdx.x;
+  if (r >= dim / 4) return;
+  double2* st = states + (size_t)blockIdx.y * dim;
+  const double2* M = gates + ((size_t)blockIdx.y * G + k) * kMat;
+  const size_t base = ((r >> lo) << (lo + 2)) | (r & (((size_t)1 << lo) - 1));
+  double2 v[4], w[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) v[b] = st[base | ((size_t)b << lo)];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    double2 s = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      double2 m = dagger ? M[b * 4 + a] : M[a * 4 + b];
+      if (dagger) m.y = -m.y;
+      s = b == 0 ? cmul(m, v[0]) : cmac(s, m, v[b]);
+    }
+    w[a] = s;
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) st[base | ((size_t)a << lo)] = w[a];
+}
+
+__device__ __forceinline__ double block_sum_sf(double v, double* red) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += shfl_xor_d(v, m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// partial[b][block] = sum over the block's amplitudes of conj(t) psi
+__global__ void __launch_bounds__(kSfThreads) k_sf_dot(const double2* target, int target_shared, const double2* psi, size_t dim,
+                                                       double2* partial) {
+  __shared__ double red[4];
+  const size_t i = (size_t)blockIdx.x * kSfThreads + threadIdx.x;
+  const double2* t = target + (target_shared ? 0 : (size_t)blockIdx.y * dim);
+  const double2* p = psi + (size_t)blockIdx.y * dim;
+  double2 c = make_double2(0.0, 0.0);
+  if (i < dim) c = cmulc(p[i], t[i]);          // psi * conj(t)
+  const double x = block_sum_sf(c.x, red), y = block_sum_sf(c.y, red);
+  if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = make_double2(x, y);
+}
+
+// fused backward step of gate k: psi <- U^H psi, E[a][b] += conj(phi[a]) psi[b], phi <- U^H phi
+__global__ void __launch_bounds__(kSfThreads) k_sf_back(double2* psi_all, double2* phi_all, size_t dim, const double2* gates, int G,
+                                                        int k, int lo, double2* partial /* [B][blocks][16] */) {
+  __shared__ double red[4];
+  const size_t r = (size_t)blockIdx.x * kSfThreads + threadIdx.x;
+  double2* psi = psi_all + (size_t)blockIdx.y * dim;
+  double2* phi = phi_all + (size_t)blockIdx.y * dim;
+  const double2* M = gates + ((size_t)blockIdx.y * G + k) * kMat;
+  double2 e[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) e[q] = make_double2(0.0, 0.0);
+  if (r < dim / 4) {
+    const size_t base = ((r >> lo) << (lo + 2)) | (r & (((size_t)1 << lo) - 1));
+    double2 p[4], f[4], pw[4], fw[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { p[b] = psi[base | ((size_t)b << lo)]; f[b] = phi[base | ((size_t)b << lo)]; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double2 sp = make_double2(0.0, 0.0), sf = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        double2 m = M[b * 4 + a];
+        m.y = -m.y;                                   // (U^H)[a][b] = conj(U[b][a])
+        sp = b == 0 ? cmul(m, p[0]) : cmac(sp, m, p[b]);
+        sf = b == 0 ? cmul(m, f[0]) : cmac(sf, m, f[b]);
+      }
+      pw[a] = sp; fw[a] = sf;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) e[a * 4 + b] = cmulc(pw[b], f[a]);     // conj(phi_k[a]) * psi_{k-1}[b]
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { psi[base | ((size_t)a << lo)] = pw[a]; phi[base | ((size_t)a << lo)] = fw[a]; }
+  }
+  double2* out = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const double x = block_sum_sf(e[q].x, red), y = block_sum_sf(e[q].y, red);
+    if (threadIdx.x == 0) out[q] = make_double2(x, y);
+  }
+}
+
+// out[b][slot * width + q] = sum over blocks (fixed order) of partial[b][block][q]
+__global__ void __launch_bounds__(kSfThreads) k_sf_reduce(const double2* partial, int nblk, int width, double2* out, int out_stride,
+                                                          int slot) {
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  for (int q = 0; q < width; ++q) {
+    double x = 0.0, y = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += kSfThreads) {
+      const double2 v = partial[((size_t)b * nblk + i) * width + q];
+      x += v.x; y += v.y;
+    }
+    x = block_sum_sf(x, red); y = block_sum_sf(y, red);
+    if (threadIdx.x == 0) out[(size_t)b * out_stride + (size_t)slot * width + q] = make_double2(x, y);
+  }
+}
+
+// ---- host side of StiefelAdam.update (stiefel_opt.py:297-347) on 4x4 complex matrices -------------------
+struct C4 { double2 a[16]; };
+inline double2 h_mul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+inline double2 h_mulc(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a conj(b)
+inline double2 h_add(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+inline double2 h_sub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+inline double2 h_inv(double2 a) { const double d = 1.0 / (a.x * a.x + a.y * a.y); return make_double2(a.x * d, -a.y * d); }
+inline double2 h_sqrt(double2 z) {         // principal branch, as numpy
+  const double ax = fabs(z.x), ay = fabs(z.y);
+  if (ax == 0.0 && ay == 0.0) return make_double2(0.0, z.y);
+  const double h = hypot(z.x, z.y), t = sqrt(0.5 * (h + ax));
+  if (z.x >= 0.0) return make_double2(t, z.y / (2.0 * t));
+  return make_double2(ay / (2.0 * t), copysign(t, z.y));
+}
+inline C4 h_matmul(const C4& A, const C4& B, bool conjT_B) {      // A * B or A * B^H
+  C4 R;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double2 s = make_double2(0.0, 0.0);
+      for (int l = 0; l < 4; ++l) s = h_add(s, conjT_B ? h_mulc(A.a[i * 4 + l], B.a[j * 4 + l]) : h_mul(A.a[i * 4 + l], B.a[l * 4 + j]));
+      R.a[i * 4 + j] = s;
+    }
+  return R;
+}
+inline C4 h_riem(const C4& g, const C4& p) {      // g - p g^H p
+  const C4 t = h_matmul(h_matmul(p, g, true), p, false);
+  C4 R;
+  for (int e = 0; e < 16; ++e) R.a[e] = h_sub(g.a[e], t.a[e]);
+  return R;
+}
+// one gate: returns the new gate, updates the moments (unless frozen) and the Frobenius norm of the change
+inline C4 h_update(const C4& p, const C4& g, C4& mom_io, C4& vel_io, bool frozen, double lr, double b1, double b2, double eps,
+                   double* dnorm) {
+  const C4 rg = h_riem(g, p);
+  double tr = 0.0;
+  for (int e = 0; e < 16; ++e) tr += rg.a[e].x * rg.a[e].x + rg.a[e].y * rg.a[e].y;      // Re tr(rg^H rg)
+  C4 mom, vel, dir;
+  for (int e = 0; e < 16; ++e) {
+    const double2 m0 = frozen ? make_double2(0.0, 0.0) : mom_io.a[e], v0 = frozen ? make_double2(0.0, 0.0) : vel_io.a[e];
+    mom.a[e] = make_double2(b1 * m0.x + (1 - b1) * rg.a[e].x, b1 * m0.y + (1 - b1) * rg.a[e].y);
+    vel.a[e] = make_double2(b2 * v0.x + (1 - b2) * tr, b2 * v0.y);                          // the scalar metric broadcast into the matrix (:325-328)
+    double2 den = h_sqrt(vel.a[e]);
+    den.x += eps;
+    dir.a[e] = h_mul(mom.a[e], h_inv(den));
+    dir.a[e] = make_double2(-lr * dir.a[e].x, -lr * dir.a[e].y);
+  }
+  // Cayley retraction (:48-57): a = g' p^H - p g'^H, new = (I - a/2)^-1 (I + a/2) p
+  const C4 gp = h_matmul(dir, p, true), pg = h_matmul(p, dir, true);
+  C4 mm, y;
+  C4 cplus;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const double2 a = h_sub(gp.a[i * 4 + j], pg.a[i * 4 + j]);
+      const double id = i == j ? 1.0 : 0.0;
+      mm.a[i * 4 + j] = make_double2(id - 0.5 * a.x, -0.5 * a.y);
+      cplus.a[i * 4 + j] = make_double2(id + 0.5 * a.x, 0.5 * a.y);
+    }
+  y = h_matmul(cplus, p, false);
+  for (int pv = 0; pv < 4; ++pv) {      // Gauss-Jordan without pivoting: the Hermitian part of (I - a/2) is the identity
+    const double2 inv = h_inv(mm.a[pv * 4 + pv]);
+    double2 mrow[4], yrow[4];
+    for (int j = 0; j < 4; ++j) { mrow[j] = mm.a[pv * 4 + j]; yrow[j] = y.a[pv * 4 + j]; }
+    for (int i = 0; i < 4; ++i) {
+      if (i == pv) {
+        for (int j = 0; j < 4; ++j) { mm.a[i * 4 + j] = h_mul(mrow[j], inv); y.a[i * 4 + j] = h_mul(yrow[j], inv); }
+      } else {
+        const double2 f = h_mul(mm.a[i * 4 + pv], inv);
+        for (int j = 0; j < 4; ++j) {
+          mm.a[i * 4 + j] = h_sub(mm.a[i * 4 + j], h_mul(f, mrow[j]));
+          y.a[i * 4 + j] = h_sub(y.a[i * 4 + j], h_mul(f, yrow[j]));
+        }
+      }
+    }
+  }
+  double df = 0.0;
+  for (int e = 0; e < 16; ++e) df += (y.a[e].x - p.a[e].x) * (y.a[e].x - p.a[e].x) + (y.a[e].y - p.a[e].y) * (y.a[e].y - p.a[e].y);
+  *dnorm = sqrt(df);
+  if (!frozen) {      // vector transport 0.5 (M - U M^H U) of both moments (:344-345)
+    const C4 tm = h_matmul(h_matmul(y, mom, true), y, false), tv = h_matmul(h_matmul(y, vel, true), y, false);
+    for (int e = 0; e < 16; ++e) {
+      mom_io.a[e] = make_double2(0.5 * (mom.a[e].x - tm.a[e].x), 0.5 * (mom.a[e].y - tm.a[e].y));
+      vel_io.a[e] = make_double2(0.5 * (vel.a[e].x - tv.a[e].x), 0.5 * (vel.a[e].y - tv.a[e].y));
+    }
+  }
+  return y;
+}
+
+}  // namespace
+
+extern "C" int mps2qc_fit_brickwork_stream(int device_id, int n, int G, const int32_t* sites, int batch, const double* target,
+                                           int target_shared, const double* init_gates, double lr, double beta1, double beta2,
+                                           double eps, int jit_frozen, int max_iter, double tol, double param_tol,
+                                           double* opt_gates, double* final_gates, double* loss_history, double* best_val,
+                                           int32_t* n_iter, double* last_envs, double* last_overlap, float* total_ms) {
+  int rc = E_OK;
+  g_err[0] = 0;
+  if (n < 2 || n > MPS2QC_STREAM_MAX_QUBITS || G < 1 || batch < 1 || max_iter < 1 || !sites || !target || !init_gates) {
+    snprintf(g_err, sizeof g_err, "mps2qc_fit_brickwork_stream: bad argument (2 <= n <= %d, G, batch, max_iter >= 1)",
+             MPS2QC_STREAM_MAX_QUBITS);
+    return E_INVAL;
+  }
+  std::vector<int> lo(G);
+  for (int k = 0; k < G; ++k) {
+    if (sites[k] < 0 || sites[k] > n - 2) {
+      snprintf(g_err, sizeof g_err, "mps2qc_fit_brickwork_stream: gate %d on sites (%d,%d) outside the register", k, sites[k], sites[k] + 1);
+      return E_INVAL;
+    }
+    lo[k] = n - 2 - sites[k];
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device_id < 0 || device_id >= ndev) {
+    snprintf(g_err, sizeof g_err, "mps2qc_fit_brickwork_stream: no usable HIP device (there is no CPU fallback)");
+    return E_NODEV;
+  }
+  const size_t dim = (size_t)1 << n;
+  const int B = batch;
+  const size_t gcount = (size_t)B * G * kMat;
+  const unsigned blk_amp = (unsigned)((dim + kSfThreads - 1) / kSfThreads), blk_vec = (unsigned)((dim / 4 + kSfThreads - 1) / kSfThreads);
+  std::vector<C4> U((size_t)B * G), Ubest((size_t)B * G), mom((size_t)B * G), vel((size_t)B * G);
+  memcpy(U.data(), init_gates, gcount * 16);
+  Ubest = U;
+  memset(mom.data(), 0, gcount * 16);
+  memset(vel.data(), 0, gcount * 16);
+  std::vector<double> bv(B, 10000.0);
+  std::vector<int> nit(B, 0), active(B, 1);
+  std::vector<double2> h_ov(B), h_env((size_t)B * G * kMat);
+  if (loss_history) memset(loss_history, 0, (size_t)B * max_iter * sizeof(double));
+
+  double2 *d_psi = nullptr, *d_phi = nullptr, *d_t = nullptr, *d_g = nullptr, *d_part = nullptr, *d_ov = nullptr, *d_env = nullptr;
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float ms = 0.f;
+  const size_t tsz = (target_shared ? 1 : (size_t)B) * dim * 16;
+  HIP_TRY(hipSetDevice(device_id));
+  HIP_TRY(hipStreamCreate(&st));
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipMalloc(&d_psi, (size_t)B * dim * 16));
+  HIP_TRY(hipMalloc(&d_phi, (size_t)B * dim * 16));
+  HIP_TRY(hipMalloc(&d_t, tsz));
+  HIP_TRY(hipMalloc(&d_g, gcount * 16));
+  HIP_TRY(hipMalloc(&d_part, (size_t)B * (blk_vec > blk_amp ? blk_vec : blk_amp) * 16 * 16));
+  HIP_TRY(hipMalloc(&d_ov, (size_t)B * 16));
+  HIP_TRY(hipMalloc(&d_env, gcount * 16));
+  HIP_TRY(hipMemcpyAsync(d_t, target, tsz, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(e0, st));
+  for (int it = 0; it < max_iter; ++it) {
+    int any = 0;
+    for (int b = 0; b < B; ++b) any |= active[b];
+    if (!any) break;
+    HIP_TRY(hipMemcpyAsync(d_g, U.data(), gcount * 16, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_sf_zero_state, dim3(blk_amp, B), dim3(kSfThreads), 0, st, d_psi, dim);
+    for (int k = 0; k < G; ++k)
+      hipLaunchKernelGGL(k_sf_apply, dim3(blk_vec, B), dim3(kSfThreads), 0, st, d_psi, dim, d_g, G, k, lo[k], 0);
+    hipLaunchKernelGGL(k_sf_dot, dim3(blk_amp, B), dim3(kSfThreads), 0, st, d_t, target_shared ? 1 : 0, d_psi, dim, d_part);
+    hipLaunchKernelGGL(k_sf_reduce, dim3(B), dim3(kSfThreads), 0, st, d_part, (int)blk_amp, 1, d_ov, 1, 0);
+    hipLaunchKernelGGL(k_sf_copy, dim3(blk_amp, B), dim3(kSfThreads), 0, st, d_phi, d_t, dim, target_shared ? 1 : 0);
+    for (int k = G - 1; k >= 0; --k) {
+      hipLaunchKernelGGL(k_sf_back, dim3(blk_vec, B), dim3(kSfThreads), 0, st, d_psi, d_phi, dim, d_g, G, k, lo[k], d_part);
+      hipLaunchKernelGGL(k_sf_reduce, dim3(B), dim3(kSfThreads), 0, st, d_part, (int)blk_vec, 16, d_env, G * kMat, k);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_ov.data(), d_ov, (size_t)B * 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_env.data(), d_env, gcount * 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const double t = jit_frozen ? 1.0 : (double)(it + 1);
+    const double lr_t = lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t));      // (stiefel_opt.py:333-335)
+    for (int b = 0; b < B; ++b) {
+      if (!active[b]) continue;
+      const double2 o = h_ov[b];
+      const double ao = hypot(o.x, o.y), val = 1.0 - ao;
+      const double2 ph = make_double2(o.x / ao, o.y / ao);
+      double dsum = 0.0;
+      for (int k = 0; k < G; ++k) {
+        C4 g;      // -(o/|o|) conj(E_k): what step() hands to update() (:107-109)
+        for (int e = 0; e < 16; ++e) {
+          const double2 E = h_env[((size_t)b * G + k) * kMat + e];
+          const double2 v = h_mul(ph, make_double2(E.x, -E.y));
+          g.a[e] = make_double2(-v.x, -v.y);
+        }
+        double dn;
+        U[(size_t)b * G + k] = h_update(U[(size_t)b * G + k], g, mom[(size_t)b * G + k], vel[(size_t)b * G + k], jit_frozen != 0, lr_t,
+                                        beta1, beta2, eps, &dn);
+        dsum += dn;
+      }
+      // bookkeeping of minimize() (:124-147)
+      if (loss_history) loss_history[(size_t)b * max_iter + it] = val;
+      nit[b] = it + 1;
+      if (val < bv[b]) {
+        bv[b] = val;
+        for (int k = 0; k < G; ++k) Ubest[(size_t)b * G + k] = U[(size_t)b * G + k];
+      }
+      if (val < tol || dsum / G < param_tol) active[b] = 0;
+    }
+  }
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (total_ms) *total_ms = ms;
+  if (opt_gates) memcpy(opt_gates, Ubest.data(), gcount * 16);
+  if (final_gates) memcpy(final_gates, U.data(), gcount * 16);
+  if (best_val) memcpy(best_val, bv.data(), B * sizeof(double));
+  if (n_iter) for (int b = 0; b < B; ++b) n_iter[b] = nit[b];
+  if (last_envs) memcpy(last_envs, h_env.data(), gcount * 16);
+  if (last_overlap) memcpy(last_overlap, h_ov.data(), (size_t)B * 16);
+
+done:
+  for (void* p : {(void*)d_psi, (void*)d_phi, (void*)d_t, (void*)d_g, (void*)d_part, (void*)d_ov, (void*)d_env}) (void)hipFree(p);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
+}

@@ -62,3 +62,24 @@ def write_init_circuit(path, num_qubits, sites, gates, rng=None):
     with open(path, "w") as f:
         f.write(text)
     return text
+
+
+def fit_state_to_init_circuit(state_little_endian, num_layers=1, max_iter=2000, n_restarts=8, rng=None, optimizer=None):
+    """Dense target state (the engine's little-endian order, e.g. a Lanczos ground state) -> brickwork fit on the GPU
+    -> the ``init_*.qasm`` text the environments read.  What ``dmrg_to_qc.py`` does with DMRG + quimb for a chi-bounded
+    MPS (dmrg-to-qc/dmrg_to_qc.py:137-223), with the exact state as the target: 2^n amplitudes are 16 MiB at 20 qubits,
+    the streaming fit kernel takes them as they are.  Returns ``(qasm_text, infidelity, gates, sites)``."""
+    from .su4_to_qasm import brickwork_to_qasm
+    psi = np.asarray(state_little_endian, complex)
+    n = int(np.log2(psi.size))
+    idx = np.arange(psi.size)
+    rev = np.zeros_like(idx)
+    for b in range(n):
+        rev |= ((idx >> b) & 1) << (n - 1 - b)
+    target = psi[rev]                                    # site 0 most significant (quimb's dense order)
+    rng = np.random.default_rng() if rng is None else rng
+    opt = optimizer or StiefelAdam(3e-2, 0.9, 0.999, 1e-8)
+    gates, hist, _ = mps_to_qc(target, {"structure": "brickwork", "num_layers": num_layers},
+                               {"method": opt, "max_iter": max_iter, "tol": 1e-10, "param_tol": 1e-9}, n_restarts=n_restarts, rng=rng)
+    sites, _ = brickwork_ansatz(n, num_layers)
+    return brickwork_to_qasm(n, sites, gates, rng), float(np.min(opt.best_val)), gates, sites

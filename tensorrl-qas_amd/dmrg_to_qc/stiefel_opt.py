@@ -29,11 +29,14 @@ class StiefelAdam:
     its ``step`` is wrapped in ``jax.jit`` and reads the optimiser state as a closed-over Python
     object, so the zero moments of ``init`` and ``iter = 1`` are trace-time constants."""
 
+    MAX_LDS_QUBITS = 12          # MPS2QC_MAX_QUBITS of include/mps2qc_hip.h: beyond, the states stream through HBM
+
     def __init__(self, learning_rate=1e-1, beta1=0.9, beta2=0.99, eps=1e-10, opt_state=None, jit_frozen=False,
-                 device_id=0, use_mfma=True):
+                 device_id=0, use_mfma=True, stream=None):
         self.learning_rate, self.beta1, self.beta2, self.eps = learning_rate, beta1, beta2, eps
         self.opt_state = {} if opt_state is None else opt_state
         self.jit_frozen, self.device_id, self.use_mfma = jit_frozen, device_id, use_mfma
+        self.stream = stream     # None: by size; True / False force the HBM-streaming / the LDS-resident kernel
 
     def init(self, params):
         self.opt_state["iter"] = 0
@@ -63,11 +66,19 @@ class StiefelAdam:
         bv, ni, ov = np.zeros(B), np.zeros(B, np.int32), np.zeros(B, np.complex128)
         ms = C.c_float(0)
         p = lambda a: a.ctypes.data_as(_lib.c_f64p)  # noqa: E731
-        rc = lib.mps2qc_fit_brickwork(
-            self.device_id, n, G, sites.ctypes.data_as(_lib.c_i32p), B, p(tgt), int(shared), p(init),
-            float(self.learning_rate), float(self.beta1), float(self.beta2), float(self.eps), int(self.jit_frozen),
-            int(max_iter), float(tol), float(param_tol), int(self.use_mfma),
-            p(opt), p(fin), p(hist), p(bv), ni.ctypes.data_as(_lib.c_i32p), p(envs), p(ov), C.byref(ms))
+        stream = (n > self.MAX_LDS_QUBITS) if self.stream is None else bool(self.stream)
+        if stream:
+            rc = lib.mps2qc_fit_brickwork_stream(
+                self.device_id, n, G, sites.ctypes.data_as(_lib.c_i32p), B, p(tgt), int(shared), p(init),
+                float(self.learning_rate), float(self.beta1), float(self.beta2), float(self.eps), int(self.jit_frozen),
+                int(max_iter), float(tol), float(param_tol),
+                p(opt), p(fin), p(hist), p(bv), ni.ctypes.data_as(_lib.c_i32p), p(envs), p(ov), C.byref(ms))
+        else:
+            rc = lib.mps2qc_fit_brickwork(
+                self.device_id, n, G, sites.ctypes.data_as(_lib.c_i32p), B, p(tgt), int(shared), p(init),
+                float(self.learning_rate), float(self.beta1), float(self.beta2), float(self.eps), int(self.jit_frozen),
+                int(max_iter), float(tol), float(param_tol), int(self.use_mfma),
+                p(opt), p(fin), p(hist), p(bv), ni.ctypes.data_as(_lib.c_i32p), p(envs), p(ov), C.byref(ms))
         if rc != 0:
             raise _lib.VQEError(f"mps2qc_fit_brickwork: {lib.mps2qc_last_error().decode()} (code {rc})")
         self.opt_state["iter"] = int(ni.max())

@@ -171,7 +171,18 @@ def apply(ham, psi):
     return out
 
 
+def ground_state(ham, tol=1e-10):
+    """(min eigenvalue, its eigenvector as complex128[2^n], little-endian) by the same matrix-free Lanczos."""
+    lo, vec = _lanczos(ham, tol, want_vector=True)
+    return lo, vec
+
+
 def extreme_eigenvalues(ham, tol=1e-10):
+    """(min, max) eigenvalue of a PauliHamiltonian: see ``_lanczos``."""
+    return _lanczos(ham, tol, want_vector=False)
+
+
+def _lanczos(ham, tol, want_vector):
     """(min, max) eigenvalue of a PauliHamiltonian by matrix-free Lanczos (scipy ``eigsh`` on a
     LinearOperator that applies the Pauli sum): replaces the reference's dense ``eigvals`` - the
     ``min_eig`` the environments subtract (environment_qulacs_TN_notin_agent.py:126-131,166-167) - where a
@@ -200,6 +211,9 @@ def extreme_eigenvalues(ham, tol=1e-10):
         return out
 
     op = LinearOperator((dim, dim), matvec=matvec, dtype=dtype)
+    if want_vector:
+        w, v = eigsh(op, k=1, which="SA", return_eigenvectors=True, tol=tol)
+        return float(np.real(w[0])), np.ascontiguousarray(v[:, 0], np.complex128)
     lo = eigsh(op, k=1, which="SA", return_eigenvectors=False, tol=tol)[0]
     hi = eigsh(op, k=1, which="LA", return_eigenvectors=False, tol=tol)[0]
     return float(np.real(lo)), float(np.real(hi))

@@ -97,7 +97,7 @@ HEIS_FIXED_CONFIG_TEMPLATE = {      # TensorRL_fixed/heisenberg_5q_TNbond2.cfg w
 }
 
 
-def write_chain_dataset(root, n, model="heisenberg", seed=20, eigvals=None, **kw):
+def write_chain_dataset(root, n, model="heisenberg", seed=20, eigvals=None, init="synthetic", fit_opts=None, **kw):
     """mol_data/<model>_<n>q.npz + init_state_circ/init_<model>_<n>q_TNbond2.qasm for the chain models the
     reference names without geometry (environment_qulacs_TN_notin_agent.py:78,122).  The Hamiltonian is the
     reference's own formula at any n (dmrg-to-qc/heisenberg_model.py:22-72; the shipped TFIM fixture) with a
@@ -112,9 +112,19 @@ def write_chain_dataset(root, n, model="heisenberg", seed=20, eigvals=None, **kw
     else:
         ham, _ = _ham.tfim(n, **kw)
         model = "tfim_j1_h0.05" if (kw.get("j", 1.0), kw.get("h")) == (1.0, 0.05) else ham.label.rsplit("_", 1)[0]
+    if init == "fit":
+        # the real thing instead of the stand-in: Lanczos ground state -> brickwork fit on the GPU -> QASM
+        # (needs a GPU; ``fit_opts`` go to dmrg_to_qc.mps2qc.fit_state_to_init_circuit)
+        from .dmrg_to_qc.mps2qc import fit_state_to_init_circuit
+        e0, psi = _ham.ground_state(ham)
+        text, infid, _, _ = fit_state_to_init_circuit(psi, rng=np.random.default_rng(seed), **(fit_opts or {}))
+        if eigvals is None:
+            eigvals = [e0, _ham.extreme_eigenvalues(ham)[1]] if n > 12 else None
+    else:
+        text = init_circuit_qasm(n, seed)
     _ham.write_npz(os.path.join(root, "mol_data", f"{model}_{n}q.npz"), ham, eigvals=eigvals)
     with open(os.path.join(root, "init_state_circ", f"init_{model}_{n}q_TNbond2.qasm"), "w") as f:
-        f.write(init_circuit_qasm(n, seed))
+        f.write(text)
     conf = copy.deepcopy(HEIS_FIXED_CONFIG_TEMPLATE)
     conf["env"].update(num_qubits=n, num_layers=27 + 40, data_root=root)
     conf["problem"]["ham_type"] = model

@@ -203,3 +203,88 @@ def fin_prev(ref, n, sites, tg, init):
     r2 = so.StiefelAdam(ref.learning_rate, ref.beta1, ref.beta2, ref.eps)
     r2.init(init)
     return r2.minimize(n, list(sites), tg, init, max_iter=2, tol=1e-30, param_tol=0.0)[3]
+
+
+# ---- HBM-streaming variant (registers beyond 12 qubits) ------------------------------------------
+@pytest.mark.parametrize("frozen", [False, True])
+@pytest.mark.parametrize("n,layers,steps", [(6, 2, 30), (12, 1, 15), (13, 1, 12), (14, 2, 8), (16, 1, 4)])
+def test_streaming_fit_matches_oracle(n, layers, steps, frozen):
+    """mps2qc_fit_brickwork_stream (states in HBM, fused backward sweep + environment reduction per gate,
+    Stiefel update on the host) against the numpy restatement: overlap / environments of the last step,
+    loss history, final and best gates - the tolerances of the LDS-resident kernel; 13 .. 16 qubits are
+    beyond MPS2QC_MAX_QUBITS, the small sizes tie the two kernels to the same oracle."""
+    from tensorrl_qas_amd import dmrg_to_qc as dq
+    rng = np.random.default_rng(31 * n + layers)
+    sites, G, tg, init = _problem(n, layers, rng, batch=2, representable=(n <= 13))
+    opt = dq.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=frozen, stream=True)
+    opt.init(init)
+    opt.minimize(dq.BrickworkOverlap(n, sites, tg), init, max_iter=steps, tol=1e-12, param_tol=1e-9)
+    for b in range(2):
+        ref = so.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=frozen)
+        ref.init(init[b])
+        bv, bp, hist, fin = ref.minimize(n, list(sites), tg[b], init[b], max_iter=steps, tol=1e-12, param_tol=1e-9)
+        assert opt.n_iter[b] == len(hist)
+        assert np.max(np.abs(np.array(opt.loss_history[b]) - np.array(hist))) < 1e-10
+        assert np.max(np.abs(opt.final_params[b] - np.array(fin))) < 1e-9
+        assert np.max(np.abs(opt.opt_params[b] - np.array(bp))) < 1e-9
+        assert abs(opt.best_val[b] - bv) < 1e-10
+        for g in opt.final_params[b]:
+            assert np.max(np.abs(g @ g.conj().T - np.eye(4))) < 1e-12
+
+
+def test_streaming_fit_equals_lds_kernel_and_defaults_by_size():
+    """Same problem through both kernels (n = 10): loss histories and gates agree to rounding; StiefelAdam picks
+    the streaming kernel by itself beyond 12 qubits; a 20-qubit fit (16 MiB states) runs and descends."""
+    from tensorrl_qas_amd import dmrg_to_qc as dq
+    rng = np.random.default_rng(5)
+    sites, G, tg, init = _problem(10, 2, rng, batch=3)
+    runs = []
+    for stream in (False, True):
+        opt = dq.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, stream=stream)
+        opt.init(init)
+        opt.minimize(dq.BrickworkOverlap(10, sites, tg), init, max_iter=40, tol=1e-12, param_tol=1e-9)
+        runs.append(opt)
+    for b in range(3):
+        assert np.max(np.abs(np.array(runs[0].loss_history[b]) - np.array(runs[1].loss_history[b]))) < 1e-11
+        assert np.max(np.abs(runs[0].final_params[b] - runs[1].final_params[b])) < 1e-10
+    n = 20
+    sites, G = dq.brickwork_ansatz(n, 1)
+    tgt = so.circuit_state(n, list(sites), so.random_unitaries(G, rng))
+    start = np.array([so.random_unitaries(G, rng)])
+    opt = dq.StiefelAdam(3e-2, 0.9, 0.999, 1e-8)                       # stream=None: by size
+    opt.init(start)
+    opt.minimize(dq.BrickworkOverlap(n, sites, tgt), start, max_iter=12, tol=1e-12, param_tol=0.0)
+    h = opt.loss_history[0]
+    assert len(h) == 12 and h[-1] < h[0] and 0.0 < h[-1] <= 1.0
+    o = np.vdot(tgt, so.circuit_state(n, list(sites), list(start[0])))
+    assert abs(h[0] - (1.0 - abs(o))) < 1e-10
+    with pytest.raises(Exception):
+        dq.StiefelAdam(3e-3, stream=False).minimize(dq.BrickworkOverlap(n, sites, tgt), start, max_iter=1)    # LDS kernel: n <= 12
+
+
+def test_ground_state_to_init_circuit_to_environment(tmp_path):
+    """The offline chain the reference runs with DMRG + quimb + qiskit (dmrg-to-qc/dmrg_to_qc.py:137-223), here for
+    a 14-qubit Heisenberg chain beyond the LDS-resident fit: generator -> Lanczos ground state -> streaming
+    brickwork fit -> {rz, ry, cx} text -> CircuitEnv.  The environment's initial energy is the energy of the
+    fitted circuit: far below the synthetic stand-in, above the ground energy, and consistent with the
+    reported fidelity (E - E0 <= (1 - F^2) (E_max - E0))."""
+    import torch
+    import tensorrl_qas_amd as tq
+    from tensorrl_qas_amd import synthetic
+    from tensorrl_qas_amd.environments.environment_qulacs_TN_notin_agent import CircuitEnv
+    n = 14
+    conf = synthetic.write_chain_dataset(str(tmp_path / "fit"), n, init="fit",
+                                         fit_opts={"max_iter": 400, "n_restarts": 4, "num_layers": 2})
+    env = CircuitEnv(conf, torch.device("cuda:0"))
+    env.reset()
+    ham, _ = tq.hamiltonian.heisenberg(n)
+    e0, psi = tq.hamiltonian.ground_state(ham)
+    assert abs(env.min_eig - e0) < 1e-8
+    fid = abs(np.vdot(psi, env.TN_state))
+    e_fit = float(env.prev_energy)
+    conf2 = synthetic.write_chain_dataset(str(tmp_path / "syn"), n, eigvals=[e0, 2 * n - 1.0])
+    env2 = CircuitEnv(conf2, torch.device("cuda:0"))
+    env2.reset()
+    assert e0 - 1e-9 <= e_fit < float(env2.prev_energy) - 1.0          # a fitted start beats a random one by a lot
+    assert fid > 0.5
+    assert e_fit - e0 <= (1.0 - fid ** 2) * (env.max_eig - e0) + 1e-9

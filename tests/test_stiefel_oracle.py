@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = sorted(set(re.findall(r"\b(mps2qc_[a-z_0-9]+)\s*\(", text)))
     lib = C.CDLL(_lib.MPS2QC_LIB_PATH)
-    assert len(names) == 3
+    assert len(names) == 4
     for name in names:
         assert hasattr(lib, name)
     assert sorted(_lib.MPS2QC_SIGNATURES) == names
