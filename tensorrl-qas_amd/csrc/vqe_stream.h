@@ -32,6 +32,7 @@ struct StreamWork {
   // LDS-tiled kernels (vqe_tile.h)
   void* passes = nullptr;     size_t passes_cap = 0;   // TilePass [batch][max_pass]
   void* opc = nullptr;        size_t opc_cap = 0;      // OpCoord [batch][max_ops]
+  void* chunks = nullptr;     size_t chunks_cap = 0;   // ChunkRec [batch][max_ops]
   int32_t* npass = nullptr;   size_t npass_cap = 0;    // [batch] op passes, [batch] energy passes
   void* epasses = nullptr;    size_t epasses_cap = 0;  // TilePass [batch][kMaxEnergyPasses]
   int32_t* eorder = nullptr;  size_t eorder_cap = 0;   // [batch][n_groups] group ids pass by pass, then [batch][n_groups] pass of a group
@@ -44,7 +45,7 @@ struct StreamWork {
   ~StreamWork() {
     (void)hipFree(states); (void)hipFree(ops); (void)hipFree(masks); (void)hipFree(meta);
     (void)hipFree(cs); (void)hipFree(gxp); (void)hipFree(tzp); (void)hipFree(tsg); (void)hipFree(partial);
-    (void)hipFree(passes); (void)hipFree(opc); (void)hipFree(npass); (void)hipFree(epasses); (void)hipFree(eorder);
+    (void)hipFree(passes); (void)hipFree(opc); (void)hipFree(chunks); (void)hipFree(npass); (void)hipFree(epasses); (void)hipFree(eorder);
     (void)hipFree(gcx); (void)hipFree(trec); (void)hipFree(grec);
   }
 };
@@ -437,6 +438,8 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
       SW_TRY(sw_reserve(tp, cap, (size_t)B * max_pass)); sw.passes = tp; sw.passes_cap = cap;
       OpCoord* oc = (OpCoord*)sw.opc; cap = sw.opc_cap;
       SW_TRY(sw_reserve(oc, cap, (size_t)B * A.max_ops)); sw.opc = oc; sw.opc_cap = cap;
+      ChunkRec* cr = (ChunkRec*)sw.chunks; cap = sw.chunks_cap;
+      SW_TRY(sw_reserve(cr, cap, (size_t)B * A.max_ops)); sw.chunks = cr; sw.chunks_cap = cap;
       tp = (TilePass*)sw.epasses; cap = sw.epasses_cap;
       SW_TRY(sw_reserve(tp, cap, (size_t)B * kMaxEnergyPasses)); sw.epasses = tp; sw.epasses_cap = cap;
     }
@@ -455,13 +458,14 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
       if (!sw.plan_ops_ok) {
         hipLaunchKernelGGL(k_s_compile, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.masks, sw.meta, eval_id);
         hipLaunchKernelGGL(k_t_plan_ops, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.meta, (TilePass*)sw.passes,
-                           (OpCoord*)sw.opc, sw.npass, max_pass);
+                           (OpCoord*)sw.opc, (ChunkRec*)sw.chunks, sw.npass, max_pass);
         sw.plan_ops_ok = !noisy;
         sw.plan_energy_ok = false;       // the Pauli masks follow the layout the circuit leaves
       }
       for (int p = 0; p < max_pass; ++p)
         hipLaunchKernelGGL(k_t_ops, dim3((unsigned)tiles, B), dim3(kThreads), 0, st, A, sw.states, sw.ops,
-                           (const OpCoord*)sw.opc, sw.cs, (const TilePass*)sw.passes, sw.npass, p, max_pass);
+                           (const OpCoord*)sw.opc, (const ChunkRec*)sw.chunks, sw.cs, (const TilePass*)sw.passes, sw.npass, p,
+                           max_pass);
     }
     if (want_energy) {
       if (!sw.plan_energy_ok) {

@@ -44,6 +44,11 @@ struct TilePass {
   uint32_t pad;
 };
 struct OpCoord { uint32_t cx, cz; };   // tile coordinates of an op's pair mask / sign mask
+constexpr int kTileK = kTileBits - 8;   // ops applied per LDS round trip: 256 threads x 2^K amplitudes = one tile
+// Coset bookkeeping of one chunk of kTileK ops (computed once by the planner; the tile kernel reads it with
+// scalar loads): slot j of the basis is the partner mask of op j when that is independent of the earlier
+// slots, else a filler unit vector; flip[j] = the op's partner as a combination of slots
+struct ChunkRec { uint32_t g[4]; uint32_t flip; uint32_t pivots; uint32_t pad[2]; };   // 32 bytes, indexed by the chunk's first op
 struct TermRec { double wr, wi; uint32_t tz, cz; };   // coefficient (incl. (-1)^{z.c}), physical Z mask, its tile coordinates
 
 // ---- basis bookkeeping of the planners (one thread per stream; arrays live in scratch: irrelevant here) ----
@@ -96,12 +101,65 @@ struct TileBasis {
 
 // ops of every stream -> passes + tile coordinates.  passes: [batch][max_pass]; opc: [batch][max_ops]
 __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, TilePass* passes, OpCoord* opc,
-                             int32_t* npass, int max_pass) {
+                             ChunkRec* chunks, int32_t* npass, int max_pass) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= A.batch) return;
   const int nops = meta[(size_t)b * 8];
   const Op* op = ops + (size_t)b * A.max_ops;
   OpCoord* oc = opc + (size_t)b * A.max_ops;
+  ChunkRec* ck = chunks + (size_t)b * A.max_ops;
+  constexpr int K = kTileK, E = 1 << K;
+  // the coset bookkeeping of k_s_opk for the ops [o, o + cnt) of a pass, in tile coordinates
+  auto plan_chunk = [&](int o, int cnt) {
+    uint32_t g[4] = {0u, 0u, 0u, 0u}, red[4] = {0u, 0u, 0u, 0u};
+    int hbit[4] = {0, 0, 0, 0}, flip[4] = {0, 0, 0, 0};
+    bool own[4] = {false, false, false, false};
+    uint32_t pivots = 0;
+    int nred = 0;
+    auto reduce = [&](uint32_t x) {
+      for (int i = 0; i < nred; ++i) if ((x >> hbit[i]) & 1u) x ^= red[i];
+      return x;
+    };
+    auto push = [&](uint32_t x) {
+      const int h = 31 - __clz((int)x);
+      for (int i = 0; i < nred; ++i) if ((red[i] >> h) & 1u) red[i] ^= x;
+      red[nred] = x; hbit[nred] = h;
+      pivots |= 1u << h;
+      ++nred;
+    };
+    for (int j = 0; j < K; ++j)
+      if (j < cnt) {
+        const int kd = op[o + j].kind & 0xff;
+        if (kd == OP_RX || kd == OP_RY) {
+          const uint32_t r = reduce(oc[o + j].cx);
+          if (r) { push(r); g[j] = oc[o + j].cx; own[j] = true; flip[j] = 1 << j; }
+        }
+      }
+    int q = 0;
+    for (int j = 0; j < K; ++j)
+      if (!own[j]) {
+        uint32_t r = 0;
+        while ((r = reduce(1u << q)) == 0) ++q;
+        push(r);
+        g[j] = 1u << q;
+        ++q;
+      }
+    for (int j = 0; j < K; ++j)
+      if (j < cnt && !own[j]) {
+        const int kd = op[o + j].kind & 0xff;
+        if (kd == OP_RX || kd == OP_RY)
+          for (int f = 1; f < E; ++f) {
+            uint32_t x = 0;
+            for (int i = 0; i < K; ++i) if ((f >> i) & 1) x ^= g[i];
+            if (x == oc[o + j].cx) flip[j] = f;
+          }
+      }
+    ChunkRec c;
+    for (int j = 0; j < 4; ++j) c.g[j] = g[j];
+    c.flip = (uint32_t)flip[0] | ((uint32_t)flip[1] << 8) | ((uint32_t)flip[2] << 16) | ((uint32_t)flip[3] << 24);
+    c.pivots = pivots; c.pad[0] = c.pad[1] = 0u;
+    ck[o] = c;
+  };
   TilePass* P = passes + (size_t)b * max_pass;
   TileBasis B;
   B.reset();
@@ -116,6 +174,7 @@ __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, Ti
         oc[o].cx = (kd == OP_RX || kd == OP_RY) ? B.coords(op[o].xm) : 0u;
         oc[o].cz = B.zcoords(op[o].zm);
       }
+      for (int o = begin; o < end; o += K) plan_chunk(o, end - o < K ? end - o : K);
     }
     ++np;
   };
@@ -238,9 +297,9 @@ __device__ __forceinline__ uint32_t tile_k_offset(const uint32_t (&basis)[kTileB
 
 // One pass of the circuit: stage the tile, apply the ops of the pass four at a time from registers, store.
 __global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states, const Op* ops, const OpCoord* opc,
-                                                    const double2* cs, const TilePass* passes, const int32_t* npass,
-                                                    int pass, int max_pass) {
-  constexpr int K = kTileBits - 8, E = 1 << K;      // 256 threads x 2^K amplitudes = one tile
+                                                    const ChunkRec* chunks, const double2* cs, const TilePass* passes,
+                                                    const int32_t* npass, int pass, int max_pass) {
+  constexpr int K = kTileK, E = 1 << K;
   __shared__ double2 tile[kTileAmps];
   const int b = blockIdx.y;
   if (pass >= npass[b]) return;
@@ -261,71 +320,35 @@ __global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states
   const int o_begin = __builtin_amdgcn_readfirstlane(P.begin), o_end = __builtin_amdgcn_readfirstlane(P.end);
   const Op* sop = ops + (size_t)b * A.max_ops;
   const OpCoord* soc = opc + (size_t)b * A.max_ops;
+  const ChunkRec* sck = chunks + (size_t)b * A.max_ops;
   const double2* csb = cs + (size_t)b * A.max_params;
   for (int o = o_begin; o < o_end; o += K) {
     const int cnt = o_end - o < K ? o_end - o : K;
-    // the coset bookkeeping of k_s_opk, in tile coordinates (kTileBits address bits)
-    Op op[K];
-    uint32_t g[K], red[K];
-    int hbit[K], flip[K];
-    uint32_t pivots = 0;
-    int nred = 0;
-    auto reduce = [&](uint32_t x) {
-#pragma unroll
-      for (int i = 0; i < K; ++i) if (i < nred && ((x >> hbit[i]) & 1u)) x ^= red[i];
-      return x;
-    };
-    auto push = [&](uint32_t x) {
-      const int h = 31 - __clz((int)x);
-#pragma unroll
-      for (int i = 0; i < K; ++i) if (i < nred && ((red[i] >> h) & 1u)) red[i] ^= x;
-#pragma unroll
-      for (int i = 0; i < K; ++i) if (i == nred) { red[i] = x; hbit[i] = h; }
-      pivots |= 1u << h;
-      ++nred;
-    };
-    bool own[K];
+    // coset bookkeeping of the chunk: made by the planner, wave-uniform here (scalar registers)
+    const ChunkRec cr = sck[o];
+    uint32_t g[K];
+    int flip[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      own[j] = false; g[j] = 0; flip[j] = 0;
+      g[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)cr.g[j]);
+      flip[j] = (__builtin_amdgcn_readfirstlane((int)cr.flip) >> (8 * j)) & 0xff;
+    }
+    const uint32_t pivots = (uint32_t)__builtin_amdgcn_readfirstlane((int)cr.pivots);
+    Op op[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      op[j] = Op{0u, 0u, 0, OP_NOP};
       if (j < cnt) {
         const Op raw = sop[o + j];
         const OpCoord c = soc[o + j];
         // sign selector of the op in tile coordinates; the part of parity(p & zm) that comes from the tile
         // origin is the same for the whole tile and goes into the op's inversion bit
-        const int inv = ((raw.kind >> 8) & 1) ^ parity32(p0 & raw.zm);
-        op[j] = Op{c.cx, c.cz, raw.pidx, (raw.kind & 0xff) | (inv << 8)};
-        const int k = op[j].kind & 0xff;
-        if (k == OP_RX || k == OP_RY) {
-          const uint32_t r = reduce(op[j].xm);
-          if (r) { push(r); g[j] = op[j].xm; own[j] = true; flip[j] = 1 << j; }
-        }
+        const int kd = __builtin_amdgcn_readfirstlane(raw.kind);
+        const int inv = ((kd >> 8) & 1) ^ parity32(p0 & (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.zm));
+        op[j] = Op{(uint32_t)__builtin_amdgcn_readfirstlane((int)c.cx), (uint32_t)__builtin_amdgcn_readfirstlane((int)c.cz),
+                   __builtin_amdgcn_readfirstlane(raw.pidx), (kd & 0xff) | (inv << 8)};
       }
     }
-    {
-      int q = 0;
-#pragma unroll
-      for (int j = 0; j < K; ++j)
-        if (!own[j]) {
-          uint32_t r = 0;
-          while ((r = reduce(1u << q)) == 0) ++q;
-          push(r);
-          g[j] = 1u << q;
-          ++q;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < K; ++j)
-      if (j < cnt && !own[j]) {
-        const int k = op[j].kind & 0xff;
-        if (k == OP_RX || k == OP_RY)
-          for (int f = 1; f < E; ++f) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int i = 0; i < K; ++i) if ((f >> i) & 1) x ^= g[i];
-            if (x == op[j].xm) flip[j] = f;
-          }
-      }
     uint32_t t0 = tid;
     for (int q = 0; q < kTileBits; ++q) if ((pivots >> q) & 1u) t0 = insert0(t0, q);
     uint32_t idx[E];
