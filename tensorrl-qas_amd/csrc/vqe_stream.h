@@ -33,6 +33,9 @@ struct StreamWork {
   void* passes = nullptr;     size_t passes_cap = 0;   // TilePass [batch][max_pass]
   void* opc = nullptr;        size_t opc_cap = 0;      // OpCoord [batch][max_ops]
   void* chunks = nullptr;     size_t chunks_cap = 0;   // ChunkRec [batch][max_ops]
+  void* egrp = nullptr;       size_t egrp_cap = 0;     // EGroupRec [batch][n_groups]
+  void* eterm = nullptr;      size_t eterm_cap = 0;    // ETermRec [batch][n_terms]
+  double* ewi = nullptr;      size_t ewi_cap = 0;      // imaginary weights [batch][n_terms]
   int32_t* npass = nullptr;   size_t npass_cap = 0;    // [batch] op passes, [batch] energy passes
   void* epasses = nullptr;    size_t epasses_cap = 0;  // TilePass [batch][kMaxEnergyPasses]
   int32_t* eorder = nullptr;  size_t eorder_cap = 0;   // [batch][n_groups] group ids pass by pass, then [batch][n_groups] pass of a group
@@ -45,7 +48,7 @@ struct StreamWork {
   ~StreamWork() {
     (void)hipFree(states); (void)hipFree(ops); (void)hipFree(masks); (void)hipFree(meta);
     (void)hipFree(cs); (void)hipFree(gxp); (void)hipFree(tzp); (void)hipFree(tsg); (void)hipFree(partial);
-    (void)hipFree(passes); (void)hipFree(opc); (void)hipFree(chunks); (void)hipFree(npass); (void)hipFree(epasses); (void)hipFree(eorder);
+    (void)hipFree(passes); (void)hipFree(opc); (void)hipFree(chunks); (void)hipFree(egrp); (void)hipFree(eterm); (void)hipFree(ewi); (void)hipFree(npass); (void)hipFree(epasses); (void)hipFree(eorder);
     (void)hipFree(gcx); (void)hipFree(trec); (void)hipFree(grec);
   }
 };
@@ -406,7 +409,7 @@ namespace vqe {
 inline bool stream_tiled(int n_groups, int n_terms) {
   static const bool env_on = [] { const char* e = getenv("VQE_STREAM_TILED"); return !(e && e[0] == '0'); }();
   return env_on && (n_groups + kTileFree - 1) / kTileFree + 1 <= kMaxEnergyPasses &&
-         sizeof(double2) * kTileAmps + sizeof(TermLds) * (size_t)(n_terms > 0 ? n_terms : 1) <= 64 * 1024;
+         n_terms <= 4096;
 }
 
 inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipStream_t st,
@@ -451,8 +454,16 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
       SW_TRY(sw_reserve(tr, cap, (size_t)B * nt)); sw.trec = tr; sw.trec_cap = cap;
     }
     SW_TRY(sw_reserve(sw.grec, sw.grec_cap, (size_t)B * ng));
+    {
+      EGroupRec* eg = (EGroupRec*)sw.egrp; size_t cap = sw.egrp_cap;
+      SW_TRY(sw_reserve(eg, cap, (size_t)B * ng)); sw.egrp = eg; sw.egrp_cap = cap;
+      ETermRec* et = (ETermRec*)sw.eterm; cap = sw.eterm_cap;
+      SW_TRY(sw_reserve(et, cap, (size_t)B * nt)); sw.eterm = et; sw.eterm_cap = cap;
+      SW_TRY(sw_reserve(sw.ewi, sw.ewi_cap, (size_t)B * nt));
+    }
     const int tiles_rank = tiles / world;
-    SW_TRY(sw_reserve(sw.partial, sw.partial_cap, (size_t)B * e_pass * tiles_rank));
+    const int e_blocks = (tiles_rank + kTilesPerBlock - 1) / kTilesPerBlock;     // k_t_energy: one partial per workgroup
+    SW_TRY(sw_reserve(sw.partial, sw.partial_cap, (size_t)B * e_pass * e_blocks));
     if (want_circuit) {
       hipLaunchKernelGGL(k_s_sincos, dim3((A.max_params + 63) / 64, B), dim3(64), 0, st, A, sw.cs);
       if (!sw.plan_ops_ok) {
@@ -474,15 +485,13 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
                            sw.gxp, sw.tzp, sw.tsg);
         hipLaunchKernelGGL(k_t_plan_energy, dim3((B + 63) / 64), dim3(64), 0, st, A, n_terms, sw.gxp, sw.tzp, sw.tsg,
                            (TilePass*)sw.epasses, sw.npass + B, sw.eorder, sw.gcx, sw.grec, (TermRec*)sw.trec,
-                           sw.eorder + (size_t)B * ng);
+                           sw.eorder + (size_t)B * ng, (EGroupRec*)sw.egrp, (ETermRec*)sw.eterm, sw.ewi);
         sw.plan_energy_ok = !noisy && sw.plan_ops_ok;
       }
-      const size_t elds = sizeof(double2) * kTileAmps + sizeof(TermLds) * (size_t)nt;
-      SW_TRY(hipFuncSetAttribute((const void*)k_t_energy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
-      hipLaunchKernelGGL(k_t_energy, dim3((unsigned)tiles_rank, B, e_pass), dim3(kThreads), elds, st, A, sw.states, n_terms,
-                         (const TilePass*)sw.epasses, sw.npass + B, sw.eorder, sw.gcx, sw.grec, (const TermRec*)sw.trec,
-                         sw.partial);
-      hipLaunchKernelGGL(k_s_reduce, dim3(B), dim3(kThreads), 0, st, sw.partial, e_pass * tiles_rank, A.fout, A.noise,
+      hipLaunchKernelGGL(k_t_energy, dim3((unsigned)e_blocks, B, e_pass), dim3(kThreads), 0, st, A, sw.states, n_terms,
+                         (const TilePass*)sw.epasses, sw.npass + B, (const EGroupRec*)sw.egrp, (const ETermRec*)sw.eterm,
+                         sw.ewi, sw.partial, tiles_rank);
+      hipLaunchKernelGGL(k_s_reduce, dim3(B), dim3(kThreads), 0, st, sw.partial, e_pass * e_blocks, A.fout, A.noise,
                          eval_id, A.amp_rank == 0 ? 1 : 0);
     }
     SW_TRY(hipGetLastError());

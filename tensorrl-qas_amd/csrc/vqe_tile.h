@@ -196,9 +196,24 @@ __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, Ti
 // X-mask groups of every stream -> passes (first fit) + tile coordinates of the groups + the term records of
 // every pass in the order the tile kernel consumes them.
 // order: [batch][n_groups] group ids pass by pass; gcx, grec: [batch][n_groups]; trec: [batch][n_terms]
+// What k_t_energy reads per group / per term, made once by the planner and fetched with SCALAR loads
+// (everything in them is the same for all threads and all tiles of the pass): every instruction a wave issues -
+// scalar, LDS or vector - costs the SIMD one issue slot, so whatever can be precomputed is.
+struct EGroupRec {            // 8 dwords
+  uint32_t cx16;              // tile coordinates of the X mask, as a byte offset (<< 4); 0: the diagonal group
+  uint32_t hb;                // highest set bit of the coordinates
+  int32_t nt;                 // its terms: the next nt records of eterm (groups and terms are stored in the order they run)
+  uint32_t im;                // some weight has an imaginary part (then wi[] is read as well)
+  uint32_t u16[4];            // byte offset of pair k of a thread: insert0(k * kThreads, hb) << 4
+};
+struct ETermRec {             // 12 dwords
+  double wr;                  // real part of the weight (pair groups: times 2, the p <-> p ^ x symmetry)
+  uint32_t cz, tz;            // sign selector in tile coordinates / physical Z mask (sign of the tile origin)
+  double sg[4];               // +-1: parity of cz with the k-th pair of a thread (pair groups)
+};
 __global__ void k_t_plan_energy(BatchArgs A, int n_terms, const uint32_t* gxp, const uint32_t* tzp, const double* tsg,
                                 TilePass* passes, int32_t* npass, int32_t* order, uint32_t* gcx, int32_t* grec,
-                                TermRec* trec, int32_t* gpass) {
+                                TermRec* trec, int32_t* gpass, EGroupRec* egrp, ETermRec* eterm, double* ewi) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= A.batch) return;
   const int ng = A.ham.n_groups;
@@ -254,18 +269,30 @@ __global__ void k_t_plan_energy(BatchArgs A, int n_terms, const uint32_t* gxp, c
     P[k].pivmask = pm; P[k].begin = pos; P[k].rec_begin = rpos; P[k].pad = 0;
     for (int g = 0; g < ng; ++g)
       if (gp[g] == k) {
-        ord[pos++] = g;
         uint32_t c = 0;
         for (int i = 0; i < kTileBits; ++i) c |= ((gx[g] >> piv[k][i]) & 1u) << i;
         gcx[(size_t)b * ng + g] = c;
         grec[(size_t)b * ng + g] = rpos - P[k].rec_begin;
+        const int hb = c ? 31 - __clz((int)c) : 0;
+        EGroupRec G;
+        G.cx16 = c << 4; G.hb = (uint32_t)hb; G.nt = A.ham.term_off[g + 1] - A.ham.term_off[g]; G.im = 0u;
+        for (int j = 0; j < 4; ++j) G.u16[j] = c ? insert0((uint32_t)j * kThreads, hb) << 4 : 0u;
         for (int t = A.ham.term_off[g]; t < A.ham.term_off[g + 1]; ++t) {
           const uint32_t z = tzp[(size_t)b * n_terms + t];
           uint32_t cz = 0;
           for (int i = 0; i < kTileBits; ++i) cz |= (uint32_t)parity32(P[k].basis[i] & z) << i;
           const double sg = tsg[(size_t)b * n_terms + t];
-          rec[rpos++] = TermRec{sg * A.ham.term_cr[t], sg * A.ham.term_ci[t], z, cz};
+          const double wr = sg * A.ham.term_cr[t], wi = sg * A.ham.term_ci[t];
+          ETermRec E;
+          E.wr = c ? 2.0 * wr : wr; E.cz = cz; E.tz = z;
+          for (int j = 0; j < 4; ++j) E.sg[j] = parity32(insert0((uint32_t)j * kThreads, hb) & cz) ? -1.0 : 1.0;
+          if (wi != 0.0) G.im = 1u;
+          eterm[(size_t)b * n_terms + rpos] = E;
+          ewi[(size_t)b * n_terms + rpos] = c ? 2.0 * wi : wi;
+          rec[rpos++] = TermRec{wr, wi, z, cz};
         }
+        egrp[(size_t)b * ng + pos] = G;
+        ord[pos++] = g;
       }
     P[k].end = pos;
     P[k].rec_count = rpos - P[k].rec_begin;
@@ -322,7 +349,11 @@ __global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states
   const OpCoord* soc = opc + (size_t)b * A.max_ops;
   const ChunkRec* sck = chunks + (size_t)b * A.max_ops;
   const double2* csb = cs + (size_t)b * A.max_params;
+#ifdef VQE_EXP_OPS_NOAPPLY
+  for (int o = o_end; o < o_end; o += K) {
+#else
   for (int o = o_begin; o < o_end; o += K) {
+#endif
     const int cnt = o_end - o < K ? o_end - o : K;
     // coset bookkeeping of the chunk: made by the planner, wave-uniform here (scalar registers)
     const ChunkRec cr = sck[o];
@@ -375,13 +406,31 @@ __global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states
 // grid = (tiles of this rank's amplitude slice, batch, passes); partial: [batch][passes][tiles].
 // Dynamic LDS: the tile (64 KiB) + the term records of the pass with the sign of the tile origin folded in
 // (per-term scalars fetched from global memory inside the group loops cost one L2 round trip per term).
-struct TermLds { double wr, wi; uint32_t cz, pad; };
+// Registers of a tile on its way between HBM and LDS.  A plain array that stays live around the tile loop is
+// left in scratch memory by the compiler (one scratch store per load, with a wait); members of a recursive
+// struct are scalars from the start.
+template <int N>
+struct TileRegs {
+  double2 v;
+  TileRegs<N - 1> rest;
+  template <class F> __device__ __forceinline__ void load(F f, int k = 0) { v = f(k); rest.load(f, k + 1); }
+  template <class F> __device__ __forceinline__ void store(F f, int k = 0) const { f(k, v); rest.store(f, k + 1); }
+};
+template <>
+struct TileRegs<0> {
+  template <class F> __device__ __forceinline__ void load(F, int = 0) {}
+  template <class F> __device__ __forceinline__ void store(F, int = 0) const {}
+};
+
+#ifndef VQE_TILES_PER_BLOCK
+#define VQE_TILES_PER_BLOCK 4
+#endif
+constexpr int kTilesPerBlock = VQE_TILES_PER_BLOCK;   // tiles a workgroup of k_t_energy walks through (the next one in flight while it computes)
 __global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double2* states, int n_terms, const TilePass* passes,
-                                                       const int32_t* npass, const int32_t* order, const uint32_t* gcx,
-                                                       const int32_t* grec, const TermRec* trec, double* partial) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
-  double2* tile = (double2*)tsm;
-  TermLds* lrec = (TermLds*)(tsm + sizeof(double2) * kTileAmps);
+                                                       const int32_t* npass, const EGroupRec* __restrict__ egrp,
+                                                       const ETermRec* __restrict__ eterm, const double* __restrict__ ewi,
+                                                       double* partial, int tiles_rank) {
+  __shared__ double2 tile[kTileAmps];
   double* red = (double*)tile;      // reused for the block reduction after the last read of the tile
   const int b = blockIdx.y, pass = blockIdx.z;
   const size_t slot = ((size_t)b * gridDim.z + pass) * gridDim.x + blockIdx.x;
@@ -395,82 +444,120 @@ __global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double
   for (int i = 0; i < kTileBits; ++i) basis[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.basis[i]);
   const uint32_t pivmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.pivmask);
   const size_t dim = (size_t)1 << A.n;
-  const uint32_t tile_id = blockIdx.x + (uint32_t)A.amp_rank * gridDim.x;     // this rank's slice of the tiles
-  const uint32_t p0 = tile_origin(tile_id, pivmask, A.n);
   const uint32_t tid = threadIdx.x;
-  const uint32_t base = p0 ^ tile_lane_offset(basis, tid);
+  const uint32_t lane_off = tile_lane_offset(basis, tid);
   const double2* psi = states + (size_t)b * dim;
-#pragma unroll
-  for (int k = 0; k < kTileAmps / kThreads; ++k) tile[tid + (uint32_t)k * kThreads] = psi[base ^ tile_k_offset(basis, k)];
-  const int nrec = __builtin_amdgcn_readfirstlane(P.rec_count);
-  const TermRec* grecs = trec + (size_t)b * n_terms + __builtin_amdgcn_readfirstlane(P.rec_begin);
-  for (int i = tid; i < nrec; i += kThreads) {
-    const TermRec r = grecs[i];
-    const bool neg = parity32(p0 & r.tz);
-    lrec[i] = TermLds{neg ? -r.wr : r.wr, neg ? -r.wi : r.wi, r.cz, 0u};
-  }
-  __syncthreads();
-  const int ng = A.ham.n_groups;
-  const int32_t* ord = order + (size_t)b * ng;
-  const uint32_t* cxs = gcx + (size_t)b * ng;
-  const int32_t* grs = grec + (size_t)b * ng;
+  constexpr int NE = kTileAmps / kThreads;           // elements per thread
+  constexpr int NPR = kTileAmps / 2 / kThreads;      // pairs per thread
+  static_assert(NPR <= 4, "ETermRec::sg holds four signs");
+  // this workgroup's tiles: blockIdx.x, blockIdx.x + gridDim.x, ... of this rank's slice.  Neighbouring tiles
+  // share their DRAM pages (a tile is 128 runs of 256 B spread over the state): workgroups that run side by side
+  // take neighbouring tiles, as a one-tile-per-workgroup grid does
+  const int t_first = (int)blockIdx.x, t_step = (int)gridDim.x, t_last = tiles_rank;
+  TileRegs<NE> stage;                                 // the next tile, on its way from HBM
+  uint32_t p0 = tile_origin((uint32_t)t_first + (uint32_t)A.amp_rank * (uint32_t)tiles_rank, pivmask, A.n);
+  stage.load([&](int k) { return psi[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
   const int g_begin = __builtin_amdgcn_readfirstlane(P.begin), g_end = __builtin_amdgcn_readfirstlane(P.end);
+  const int r_begin = __builtin_amdgcn_readfirstlane(P.rec_begin), r_count = __builtin_amdgcn_readfirstlane(P.rec_count);
+  const EGroupRec* __restrict__ G = egrp + (size_t)b * A.ham.n_groups + g_begin;
+  const ETermRec* __restrict__ T = eterm + (size_t)b * n_terms + r_begin;
+  const double* __restrict__ WI = ewi + (size_t)b * n_terms + r_begin;
+  const int n_in_pass = g_end - g_begin;
+  lds_cbyte* tile_b = (lds_cbyte*)tile;
   double acc = 0.0;
-  for (int gi = g_begin; gi < g_end; ++gi) {
-    const int g = __builtin_amdgcn_readfirstlane(ord[gi]);
-    const uint32_t cx = (uint32_t)__builtin_amdgcn_readfirstlane((int)cxs[g]);
-    const int nt = A.ham.term_off[g + 1] - A.ham.term_off[g];
-    const TermLds* lr = lrec + __builtin_amdgcn_readfirstlane(grs[g]);
-    // Sign sums D(t) = sum_terms w (-1)^{parity(t & cz)}.  The tile elements (pair representatives) of a
-    // thread are t_k = t_0 ^ U_k with U_k THE SAME FOR EVERY THREAD (k only moves index bits above the
-    // thread id), so parity(t_k & cz) = parity(t_0 & cz) ^ parity(U_k & cz): one vector parity per term,
-    // the k-dependence is a scalar +-1 folded into an FMA.
-    if (cx == 0) {          // diagonal group
-      constexpr int NE = kTileAmps / kThreads;
-      double d[NE];
+  // One group: its record and its first two term records are in scalar registers already (requested one group
+  // ahead: a scalar load that misses its cache takes ~600 cycles, as long as the whole group)
+  struct Blob { EGroupRec g; ETermRec t0, t1; };
+  auto fetch = [&](Blob& B, int gi, int cur) {
+    B.g = G[gi < n_in_pass ? gi : n_in_pass - 1];
+    B.t0 = T[cur < r_count ? cur : 0];
+    B.t1 = T[cur + 1 < r_count ? cur + 1 : 0];
+  };
+  for (int tl = t_first; tl < t_last; tl += t_step) {
+    if (tl != t_first) __syncthreads();                 // the previous tile has been read to the end
+    stage.store([&](int k, const double2& v) { tile[tid + (uint32_t)k * kThreads] = v; });
+    __syncthreads();
+    const uint32_t pt = p0;                             // origin of the tile being evaluated
+    if (tl + t_step < t_last) {                         // request the next tile: it lands while this one is evaluated
+      p0 = tile_origin((uint32_t)(tl + t_step) + (uint32_t)A.amp_rank * (uint32_t)tiles_rank, pivmask, A.n);
+      stage.load([&](int k) { return psi[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
+    }
+    // Sign sums D_k = sum_terms w (-1)^{parity(t_k & cz)}: the elements of a thread are t_k = t_0 ^ U_k with
+    // U_k the same for every thread, so parity(t_k & cz) = parity(t_0 & cz) ^ parity(U_k & cz): one vector
+    // parity per term, the k-dependence is the record's +-1 (a scalar operand of the FMA); the sign of the
+    // tile origin, parity(pt & tz), is a scalar too
+    auto signed_w = [&](double w, uint32_t t0, uint32_t cz, uint32_t tz) {
+      const uint32_t flip = ((uint32_t)__builtin_popcount(t0 & cz) ^ (uint32_t)__builtin_popcount(pt & tz)) << 31;
+      return __hiloint2double(__double2hiint(w) ^ (int)flip, __double2loint(w));
+    };
+    auto body = [&](const Blob& B, int cur) {
+      const uint32_t cx16 = B.g.cx16;
+      const int nt = B.g.nt;
+      if (cx16 == 0) {          // diagonal group (one per Hamiltonian shard: records fetched as they are needed)
+        double2 a[NE];
 #pragma unroll
-      for (int k = 0; k < NE; ++k) d[k] = 0.0;
-      for (int t = 0; t < nt; ++t) {
-        const TermLds r = lr[t];
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.cz);
-        const double w = r.wr;
-        const double v = parity32(tid & c) ? -w : w;
+        for (int k = 0; k < NE; ++k) a[k] = tile[tid + (uint32_t)k * kThreads];
+        double d[NE];
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
-          const double sg = (__builtin_popcount(((uint32_t)k * kThreads) & c) & 1) ? -1.0 : 1.0;   // uniform
-          d[k] = fma(sg, v, d[k]);
+        for (int k = 0; k < NE; ++k) d[k] = 0.0;
+        for (int t = 0; t < nt; ++t) {
+          const uint32_t cz = T[cur + t].cz;
+          const double v = signed_w(T[cur + t].wr, tid, cz, T[cur + t].tz);
+#pragma unroll
+          for (int k = 0; k < NE; ++k) d[k] += (__builtin_popcount(((uint32_t)k * kThreads) & cz) & 1) ? -v : v;
         }
-      }
 #pragma unroll
-      for (int k = 0; k < NE; ++k) {
-        const double2 a = tile[tid + (uint32_t)k * kThreads];
-        acc += (a.x * a.x + a.y * a.y) * d[k];
+        for (int k = 0; k < NE; ++k) acc = fma(a[k].x * a[k].x + a[k].y * a[k].y, d[k], acc);
+        return;
       }
-    } else {
-      const int hb = 31 - __clz((int)cx);
-      constexpr int NPR = kTileAmps / 2 / kThreads;      // pairs per thread
-      const uint32_t tr0 = insert0(tid, hb);
-      double dr[NPR], di[NPR];
-#pragma unroll
-      for (int k = 0; k < NPR; ++k) { dr[k] = 0.0; di[k] = 0.0; }
-      for (int t = 0; t < nt; ++t) {
-        const TermLds r = lr[t];
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.cz);
-        const double wr = r.wr, wi = r.wi;
-        const bool neg = parity32(tr0 & c);
-        const double vr = neg ? -wr : wr, vi = neg ? -wi : wi;
-#pragma unroll
-        for (int k = 0; k < NPR; ++k) {
-          const double sg = (__builtin_popcount(insert0((uint32_t)k * kThreads, hb) & c) & 1) ? -1.0 : 1.0;   // uniform
-          dr[k] = fma(sg, vr, dr[k]);
-          di[k] = fma(sg, vi, di[k]);
-        }
-      }
+      const uint32_t a0 = insert0(tid, (int)B.g.hb) << 4;
+      // both members of the thread's pairs: requested before the sign sums, consumed after them
+      double2 pa[NPR], pb[NPR];
 #pragma unroll
       for (int k = 0; k < NPR; ++k) {
-        const uint32_t tr = tr0 ^ insert0((uint32_t)k * kThreads, hb);
-        const double2 bb = tile[tr], a = tile[tr ^ cx];
-        acc += 2.0 * ((a.x * bb.x + a.y * bb.y) * dr[k] - (a.x * bb.y - a.y * bb.x) * di[k]);
+        const uint32_t off = k ? a0 ^ B.g.u16[k] : a0;
+        pb[k] = lds_load_d2(tile_b, off);
+        pa[k] = lds_load_d2(tile_b, off ^ cx16);
+      }
+      const uint32_t t0 = a0 >> 4;
+      double dr[NPR];
+#pragma unroll
+      for (int k = 0; k < NPR; ++k) dr[k] = 0.0;
+      auto term = [&](const ETermRec& r) {
+        const double v = signed_w(r.wr, t0, r.cz, r.tz);
+#pragma unroll
+        for (int k = 0; k < NPR; ++k) dr[k] = fma(r.sg[k], v, dr[k]);
+      };
+      if (nt > 0) term(B.t0);
+      if (nt > 1) term(B.t1);
+      for (int t = 2; t < nt; ++t) term(T[cur + t]);
+#pragma unroll
+      for (int k = 0; k < NPR; ++k) acc = fma(pa[k].x * pb[k].x + pa[k].y * pb[k].y, dr[k], acc);
+      if (B.g.im) {            // imaginary parts of the weights (odd number of Y factors): rare
+        double di[NPR];
+#pragma unroll
+        for (int k = 0; k < NPR; ++k) di[k] = 0.0;
+        for (int t = 0; t < nt; ++t) {
+          const double v = signed_w(WI[cur + t], t0, T[cur + t].cz, T[cur + t].tz);
+#pragma unroll
+          for (int k = 0; k < NPR; ++k) di[k] = fma(T[cur + t].sg[k], v, di[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < NPR; ++k) acc -= (pa[k].x * pb[k].y - pa[k].y * pb[k].x) * di[k];
+      }
+    };
+    if (n_in_pass > 0) {
+      Blob B0, B1;
+      int c0 = 0, c1 = 0;
+      fetch(B0, 0, 0);
+      for (int gi = 0; gi < n_in_pass; gi += 2) {
+        c1 = c0 + B0.g.nt;
+        fetch(B1, gi + 1, c1);
+        body(B0, c0);
+        if (gi + 1 >= n_in_pass) break;
+        c0 = c1 + B1.g.nt;
+        fetch(B0, gi + 2, c0);
+        body(B1, c1);
       }
     }
   }
