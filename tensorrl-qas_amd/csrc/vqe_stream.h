@@ -36,6 +36,7 @@ struct StreamWork {
   void* egrp = nullptr;       size_t egrp_cap = 0;     // EGroupRec [batch][n_groups]
   void* eterm = nullptr;      size_t eterm_cap = 0;    // ETermRec [batch][n_terms]
   double* ewi = nullptr;      size_t ewi_cap = 0;      // imaginary weights [batch][n_terms]
+  double2* csop = nullptr;    size_t csop_cap = 0;     // (cos, sin) in op order [batch][max_ops]
   int32_t* npass = nullptr;   size_t npass_cap = 0;    // [batch] op passes, [batch] energy passes
   void* epasses = nullptr;    size_t epasses_cap = 0;  // TilePass [batch][kMaxEnergyPasses]
   int32_t* eorder = nullptr;  size_t eorder_cap = 0;   // [batch][n_groups] group ids pass by pass, then [batch][n_groups] pass of a group
@@ -48,7 +49,7 @@ struct StreamWork {
   ~StreamWork() {
     (void)hipFree(states); (void)hipFree(ops); (void)hipFree(masks); (void)hipFree(meta);
     (void)hipFree(cs); (void)hipFree(gxp); (void)hipFree(tzp); (void)hipFree(tsg); (void)hipFree(partial);
-    (void)hipFree(passes); (void)hipFree(opc); (void)hipFree(chunks); (void)hipFree(egrp); (void)hipFree(eterm); (void)hipFree(ewi); (void)hipFree(npass); (void)hipFree(epasses); (void)hipFree(eorder);
+    (void)hipFree(passes); (void)hipFree(opc); (void)hipFree(chunks); (void)hipFree(egrp); (void)hipFree(eterm); (void)hipFree(ewi); (void)hipFree(csop); (void)hipFree(npass); (void)hipFree(epasses); (void)hipFree(eorder);
     (void)hipFree(gcx); (void)hipFree(trec); (void)hipFree(grec);
   }
 };
@@ -443,6 +444,7 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
       SW_TRY(sw_reserve(oc, cap, (size_t)B * A.max_ops)); sw.opc = oc; sw.opc_cap = cap;
       ChunkRec* cr = (ChunkRec*)sw.chunks; cap = sw.chunks_cap;
       SW_TRY(sw_reserve(cr, cap, (size_t)B * A.max_ops)); sw.chunks = cr; sw.chunks_cap = cap;
+      SW_TRY(sw_reserve(sw.csop, sw.csop_cap, (size_t)B * A.max_ops));
       tp = (TilePass*)sw.epasses; cap = sw.epasses_cap;
       SW_TRY(sw_reserve(tp, cap, (size_t)B * kMaxEnergyPasses)); sw.epasses = tp; sw.epasses_cap = cap;
     }
@@ -473,10 +475,12 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
         sw.plan_ops_ok = !noisy;
         sw.plan_energy_ok = false;       // the Pauli masks follow the layout the circuit leaves
       }
+      hipLaunchKernelGGL(k_t_cs_ops, dim3((A.max_ops + 63) / 64, B), dim3(64), 0, st, A, sw.ops, sw.meta, sw.cs, sw.csop);
+      const int o_blocks = (tiles + kOpsTilesPerBlock - 1) / kOpsTilesPerBlock;
       for (int p = 0; p < max_pass; ++p)
-        hipLaunchKernelGGL(k_t_ops, dim3((unsigned)tiles, B), dim3(kThreads), 0, st, A, sw.states, sw.ops,
-                           (const OpCoord*)sw.opc, (const ChunkRec*)sw.chunks, sw.cs, (const TilePass*)sw.passes, sw.npass, p,
-                           max_pass);
+        hipLaunchKernelGGL(k_t_ops, dim3((unsigned)o_blocks, B), dim3(kThreads), 0, st, A, sw.states,
+                           (const ChunkRec*)sw.chunks, (const double2*)sw.csop, (const TilePass*)sw.passes, sw.npass, p,
+                           max_pass, tiles);
     }
     if (want_energy) {
       if (!sw.plan_energy_ok) {

@@ -45,10 +45,17 @@ struct TilePass {
 };
 struct OpCoord { uint32_t cx, cz; };   // tile coordinates of an op's pair mask / sign mask
 constexpr int kTileK = kTileBits - 8;   // ops applied per LDS round trip: 256 threads x 2^K amplitudes = one tile
-// Coset bookkeeping of one chunk of kTileK ops (computed once by the planner; the tile kernel reads it with
-// scalar loads): slot j of the basis is the partner mask of op j when that is independent of the earlier
-// slots, else a filler unit vector; flip[j] = the op's partner as a combination of slots
-struct ChunkRec { uint32_t g[4]; uint32_t flip; uint32_t pivots; uint32_t pad[2]; };   // 32 bytes, indexed by the chunk's first op
+// One chunk of kTileK ops as k_t_ops wants it (made once by the planner, read with scalar loads): slot j of the
+// thread's coset basis is the partner mask of op j when that is independent of the earlier slots, else a filler
+// unit vector (the bookkeeping of k_s_opk, in tile coordinates).
+struct ChunkRec {             // 16 dwords, indexed by the chunk's first op
+  uint32_t g16[3];            // slot masks as byte offsets (<< 4)
+  uint32_t pvc;               // pivot positions of the reduced slot basis, ascending, 5 bits each | number of ops << 16
+  struct {
+    uint32_t kfe;             // kind | flip code << 4 (partner of element e: e ^ flip) | inversion << 8 | ebits << 16
+    uint32_t cz, zm;          // sign selector in tile coordinates / the op's physical Z mask (sign of the tile origin)
+  } op[4];                    // ebits: bit e = parity(cz & combination e of the slot masks)
+};
 struct TermRec { double wr, wi; uint32_t tz, cz; };   // coefficient (incl. (-1)^{z.c}), physical Z mask, its tile coordinates
 
 // ---- basis bookkeeping of the planners (one thread per stream; arrays live in scratch: irrelevant here) ----
@@ -100,6 +107,7 @@ struct TileBasis {
 };
 
 // ops of every stream -> passes + tile coordinates.  passes: [batch][max_pass]; opc: [batch][max_ops]
+static_assert(sizeof(ChunkRec) == 64 && kTileK <= 3, "ChunkRec: three slots, sixteen dwords");
 __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, TilePass* passes, OpCoord* opc,
                              ChunkRec* chunks, int32_t* npass, int max_pass) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,9 +163,29 @@ __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, Ti
           }
       }
     ChunkRec c;
-    for (int j = 0; j < 4; ++j) c.g[j] = g[j];
-    c.flip = (uint32_t)flip[0] | ((uint32_t)flip[1] << 8) | ((uint32_t)flip[2] << 16) | ((uint32_t)flip[3] << 24);
-    c.pivots = pivots; c.pad[0] = c.pad[1] = 0u;
+    for (int j = 0; j < 3; ++j) c.g16[j] = g[j] << 4;
+    uint32_t pvc = (uint32_t)cnt << 16;
+    {
+      int k = 0;
+      for (int qb = 0; qb < kTileBits; ++qb) if ((pivots >> qb) & 1u) { pvc |= (uint32_t)qb << (5 * k); ++k; }
+    }
+    c.pvc = pvc;
+    for (int j = 0; j < 4; ++j) {
+      c.op[j].kfe = OP_NOP; c.op[j].cz = 0u; c.op[j].zm = 0u;
+      if (j < cnt) {
+        const uint32_t cz = oc[o + j].cz;
+        uint32_t ebits = 0;
+        for (int e = 0; e < E; ++e) {
+          uint32_t x = 0;
+          for (int i = 0; i < K; ++i) if ((e >> i) & 1) x ^= g[i];
+          ebits |= (uint32_t)parity32(x & cz) << e;
+        }
+        c.op[j].kfe = (uint32_t)(op[o + j].kind & 0xf) | ((uint32_t)flip[j] << 4) | ((uint32_t)((op[o + j].kind >> 8) & 1) << 8) |
+                      (ebits << 16);
+        c.op[j].cz = cz;
+        c.op[j].zm = op[o + j].zm;
+      }
+    }
     ck[o] = c;
   };
   TilePass* P = passes + (size_t)b * max_pass;
@@ -323,89 +351,6 @@ __device__ __forceinline__ uint32_t tile_k_offset(const uint32_t (&basis)[kTileB
 }
 
 // One pass of the circuit: stage the tile, apply the ops of the pass four at a time from registers, store.
-__global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states, const Op* ops, const OpCoord* opc,
-                                                    const ChunkRec* chunks, const double2* cs, const TilePass* passes,
-                                                    const int32_t* npass, int pass, int max_pass) {
-  constexpr int K = kTileK, E = 1 << K;
-  __shared__ double2 tile[kTileAmps];
-  const int b = blockIdx.y;
-  if (pass >= npass[b]) return;
-  const TilePass P = passes[(size_t)b * max_pass + pass];
-  uint32_t basis[kTileBits];
-#pragma unroll
-  for (int i = 0; i < kTileBits; ++i) basis[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.basis[i]);
-  const uint32_t pivmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.pivmask);
-  const size_t dim = (size_t)1 << A.n;
-  const uint32_t p0 = tile_origin(blockIdx.x, pivmask, A.n);
-  const uint32_t tid = threadIdx.x;
-  const uint32_t base = p0 ^ tile_lane_offset(basis, tid);
-  double2* psi = states + (size_t)b * dim;
-  const double2* src = pass == 0 ? A.init : psi;      // the first pass starts from the shared initial state
-#pragma unroll
-  for (int k = 0; k < kTileAmps / kThreads; ++k) tile[tid + (uint32_t)k * kThreads] = src[base ^ tile_k_offset(basis, k)];
-  __syncthreads();
-  const int o_begin = __builtin_amdgcn_readfirstlane(P.begin), o_end = __builtin_amdgcn_readfirstlane(P.end);
-  const Op* sop = ops + (size_t)b * A.max_ops;
-  const OpCoord* soc = opc + (size_t)b * A.max_ops;
-  const ChunkRec* sck = chunks + (size_t)b * A.max_ops;
-  const double2* csb = cs + (size_t)b * A.max_params;
-#ifdef VQE_EXP_OPS_NOAPPLY
-  for (int o = o_end; o < o_end; o += K) {
-#else
-  for (int o = o_begin; o < o_end; o += K) {
-#endif
-    const int cnt = o_end - o < K ? o_end - o : K;
-    // coset bookkeeping of the chunk: made by the planner, wave-uniform here (scalar registers)
-    const ChunkRec cr = sck[o];
-    uint32_t g[K];
-    int flip[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      g[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)cr.g[j]);
-      flip[j] = (__builtin_amdgcn_readfirstlane((int)cr.flip) >> (8 * j)) & 0xff;
-    }
-    const uint32_t pivots = (uint32_t)__builtin_amdgcn_readfirstlane((int)cr.pivots);
-    Op op[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      op[j] = Op{0u, 0u, 0, OP_NOP};
-      if (j < cnt) {
-        const Op raw = sop[o + j];
-        const OpCoord c = soc[o + j];
-        // sign selector of the op in tile coordinates; the part of parity(p & zm) that comes from the tile
-        // origin is the same for the whole tile and goes into the op's inversion bit
-        const int kd = __builtin_amdgcn_readfirstlane(raw.kind);
-        const int inv = ((kd >> 8) & 1) ^ parity32(p0 & (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.zm));
-        op[j] = Op{(uint32_t)__builtin_amdgcn_readfirstlane((int)c.cx), (uint32_t)__builtin_amdgcn_readfirstlane((int)c.cz),
-                   __builtin_amdgcn_readfirstlane(raw.pidx), (kd & 0xff) | (inv << 8)};
-      }
-    }
-    uint32_t t0 = tid;
-    for (int q = 0; q < kTileBits; ++q) if ((pivots >> q) & 1u) t0 = insert0(t0, q);
-    uint32_t idx[E];
-    double2 v[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      uint32_t x = t0;
-#pragma unroll
-      for (int i = 0; i < K; ++i) if ((e >> i) & 1) x ^= g[i];
-      idx[e] = x;
-      v[e] = tile[x];
-    }
-#pragma unroll
-    for (int j = 0; j < K; ++j) if (j < cnt) s_apply_k<K>(v, idx, op[j], csb, j, flip[j]);
-#pragma unroll
-    for (int e = 0; e < E; ++e) tile[idx[e]] = v[e];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int k = 0; k < kTileAmps / kThreads; ++k) psi[base ^ tile_k_offset(basis, k)] = tile[tid + (uint32_t)k * kThreads];
-}
-
-// <psi|H_shard|psi>: every pass stages each tile once (read only) and evaluates all its X-mask groups from LDS.
-// grid = (tiles of this rank's amplitude slice, batch, passes); partial: [batch][passes][tiles].
-// Dynamic LDS: the tile (64 KiB) + the term records of the pass with the sign of the tile origin folded in
-// (per-term scalars fetched from global memory inside the group loops cost one L2 round trip per term).
 // Registers of a tile on its way between HBM and LDS.  A plain array that stays live around the tile loop is
 // left in scratch memory by the compiler (one scratch store per load, with a wait); members of a recursive
 // struct are scalars from the start.
@@ -422,6 +367,154 @@ struct TileRegs<0> {
   template <class F> __device__ __forceinline__ void store(F, int = 0) const {}
 };
 
+// (cos, sin) of every op's parameter in op order: k_t_ops reads them next to the chunk records, with no
+// dependent load through the parameter index
+__global__ void k_t_cs_ops(BatchArgs A, const Op* ops, const int32_t* meta, const double2* cs, double2* csop) {
+  const int b = blockIdx.y;
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= meta[(size_t)b * 8]) return;
+  const Op op = ops[(size_t)b * A.max_ops + o];
+  const int kd = op.kind & 0xff;
+  csop[(size_t)b * A.max_ops + o] =
+      (kd == OP_RX || kd == OP_RY || kd == OP_RZ) ? cs[(size_t)b * A.max_params + op.pidx] : make_double2(1.0, 0.0);
+}
+
+#ifndef VQE_OPS_TILES_PER_BLOCK
+#define VQE_OPS_TILES_PER_BLOCK 4
+#endif
+constexpr int kOpsTilesPerBlock = VQE_OPS_TILES_PER_BLOCK;
+// sign-flipped copy of s: bit 31 of `flipword` decides
+__device__ __forceinline__ double t_flip(double s, uint32_t flipword) {
+  return __hiloint2double(__double2hiint(s) ^ (int)(flipword & 0x80000000u), __double2loint(s));
+}
+// w[e] = c v[e] + s(e) v[e ^ F]: the per-element updates of s_apply_k (vqe_stream.h), same expressions
+template <int E, int F>
+__device__ __forceinline__ void t_rot_pairs(const double2 (&v)[E], double2 (&w)[E], bool rx, double c, double s, uint32_t fw,
+                                            uint32_t ebits) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const double2 a = v[e], bq = v[e ^ F];
+    if (rx) w[e] = make_double2(c * a.x - s * bq.y, c * a.y + s * bq.x);
+    else {
+      const double sg = t_flip(s, fw ^ (ebits << (31 - e)));
+      w[e] = make_double2(c * a.x + sg * bq.x, c * a.y + sg * bq.y);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states, const ChunkRec* __restrict__ chunks,
+                                                    const double2* __restrict__ csop, const TilePass* passes,
+                                                    const int32_t* npass, int pass, int max_pass, int tiles) {
+  constexpr int K = kTileK, E = 1 << K;
+  constexpr int NE = kTileAmps / kThreads;
+  static_assert(E == 8 && NE == 8, "k_t_ops: three ops per chunk, eight amplitudes per thread");
+  __shared__ double2 tile[kTileAmps];
+  const int b = blockIdx.y;
+  if (pass >= npass[b]) return;
+  const TilePass P = passes[(size_t)b * max_pass + pass];
+  uint32_t basis[kTileBits];
+#pragma unroll
+  for (int i = 0; i < kTileBits; ++i) basis[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.basis[i]);
+  const uint32_t pivmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.pivmask);
+  const size_t dim = (size_t)1 << A.n;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane_off = tile_lane_offset(basis, tid);
+  double2* psi = states + (size_t)b * dim;
+  const double2* src = pass == 0 ? A.init : psi;      // the first pass starts from the shared initial state
+  const int o_begin = __builtin_amdgcn_readfirstlane(P.begin), o_end = __builtin_amdgcn_readfirstlane(P.end);
+  const ChunkRec* __restrict__ CH = chunks + (size_t)b * A.max_ops;
+  const double2* __restrict__ CS = csop + (size_t)b * A.max_ops;
+  lds_cbyte* tile_rb = (lds_cbyte*)tile;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+  lds_byte_t* tile_wb = (lds_byte_t*)tile;
+  // tiles blockIdx.x, blockIdx.x + gridDim.x, ... (see k_t_energy); the next one is in flight while this one is worked on
+  const int t_first = (int)blockIdx.x, t_step = (int)gridDim.x, t_last = tiles;
+  TileRegs<NE> stage;
+  uint32_t p0 = tile_origin((uint32_t)t_first, pivmask, A.n);
+  stage.load([&](int k) { return src[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
+  for (int tl = t_first; tl < t_last; tl += t_step) {
+    if (tl != t_first) __syncthreads();                 // the previous tile has left the LDS
+    stage.store([&](int k, const double2& v) { tile[tid + (uint32_t)k * kThreads] = v; });
+    __syncthreads();
+    const uint32_t pt = p0;
+    if (tl + t_step < t_last) {
+      p0 = tile_origin((uint32_t)(tl + t_step), pivmask, A.n);
+      stage.load([&](int k) { return src[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
+    }
+    for (int o = o_begin; o < o_end; o += K) {
+      const ChunkRec& cr = CH[o];
+      const uint32_t pvc = cr.pvc;
+      const int cnt = (int)(pvc >> 16);
+      // the thread's coset: zeros inserted into tid at the pivot positions, then the 2^K combinations of the slot masks
+      uint32_t t0 = tid;
+#pragma unroll
+      for (int i = 0; i < K; ++i) t0 = insert0(t0, (int)((pvc >> (5 * i)) & 31u));
+      const uint32_t a0 = t0 << 4;
+      uint32_t off[E];
+      double2 v[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) if ((e >> i) & 1) x ^= cr.g16[i];
+        off[e] = a0 ^ x;
+        v[e] = lds_load_d2(tile_rb, off[e]);
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        if (j >= cnt) break;
+        const uint32_t kfe = cr.op[j].kfe;
+        const int kind = (int)(kfe & 0xfu), flip = (int)((kfe >> 4) & 0xfu);
+        const uint32_t ebits = kfe >> 16;
+        const double2 c = CS[o + j];
+        // sign of element e: parity(t0 & cz) [vector] ^ ebits[e] ^ parity(tile origin & zm) ^ inversion [scalars]
+        const uint32_t fw = ((uint32_t)__builtin_popcount(t0 & cr.op[j].cz) +
+                             ((uint32_t)__builtin_popcount(pt & cr.op[j].zm) ^ ((kfe >> 8) & 1u))) << 31;
+        if (kind == OP_RX || kind == OP_RY) {
+          double2 w[E];
+          const bool rx = kind == OP_RX;
+          switch (flip) {
+            case 1: t_rot_pairs<E, 1>(v, w, rx, c.x, c.y, fw, ebits); break;
+            case 2: t_rot_pairs<E, 2>(v, w, rx, c.x, c.y, fw, ebits); break;
+            case 3: t_rot_pairs<E, 3>(v, w, rx, c.x, c.y, fw, ebits); break;
+            case 4: t_rot_pairs<E, 4>(v, w, rx, c.x, c.y, fw, ebits); break;
+            case 5: t_rot_pairs<E, 5>(v, w, rx, c.x, c.y, fw, ebits); break;
+            case 6: t_rot_pairs<E, 6>(v, w, rx, c.x, c.y, fw, ebits); break;
+            default: t_rot_pairs<E, 7>(v, w, rx, c.x, c.y, fw, ebits); break;
+          }
+#pragma unroll
+          for (int e = 0; e < E; ++e) v[e] = w[e];
+        } else if (kind == OP_RZ) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const double sg = t_flip(c.y, fw ^ (ebits << (31 - e)));
+            const double2 a = v[e];
+            v[e] = make_double2(c.x * a.x - sg * a.y, c.x * a.y + sg * a.x);
+          }
+        } else if (kind == OP_PZ) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const uint32_t f = fw ^ (ebits << (31 - e));
+            v[e] = make_double2(t_flip(v[e].x, f), t_flip(v[e].y, f));
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        d2v_t q; q.x = v[e].x; q.y = v[e].y;
+        *(__attribute__((address_space(3))) d2v_t*)(tile_wb + off[e]) = q;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) psi[(pt ^ lane_off) ^ tile_k_offset(basis, k)] = tile[tid + (uint32_t)k * kThreads];
+  }
+}
+
+// <psi|H_shard|psi>: every pass stages each tile once (read only) and evaluates all its X-mask groups from LDS.
+// grid = (tiles of this rank's amplitude slice, batch, passes); partial: [batch][passes][tiles].
+// Dynamic LDS: the tile (64 KiB) + the term records of the pass with the sign of the tile origin folded in
+// (per-term scalars fetched from global memory inside the group loops cost one L2 round trip per term).
 #ifndef VQE_TILES_PER_BLOCK
 #define VQE_TILES_PER_BLOCK 4
 #endif
