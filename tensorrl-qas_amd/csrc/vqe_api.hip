@@ -889,7 +889,7 @@ int vqe_set_amplitude_shard(vqe_t* h, int rank, int world) {
   if (world < 1 || rank < 0 || rank >= world) return fail(h, VQE_EINVAL, "bad shard rank/world");
   if (h->lds_path && world > 1)
     return fail(h, VQE_ESTATE, "amplitude sharding of the energy sweep exists on the streaming path (n >= 14); use vqe_set_term_shard");
-  const size_t blocks = ((size_t)1 << h->n) >> kTileBits;      // tiles of the energy sweep (vqe_tile.h)
+  const size_t blocks = ((size_t)1 << h->n) >> kETileBits;     // tiles of the energy sweep (vqe_tile.h)
   if (!h->lds_path && (blocks % (size_t)world) != 0) return fail(h, VQE_EINVAL, "world must divide the number of sweep tiles of the energy reduction");
   h->amp_rank = rank;
   h->amp_world = world;

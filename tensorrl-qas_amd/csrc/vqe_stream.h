@@ -409,7 +409,7 @@ namespace vqe {
 // X-mask groups for the pass table) selects the one-sweep-per-four-ops kernels above.
 inline bool stream_tiled(int n_groups, int n_terms) {
   static const bool env_on = [] { const char* e = getenv("VQE_STREAM_TILED"); return !(e && e[0] == '0'); }();
-  return env_on && (n_groups + kTileFree - 1) / kTileFree + 1 <= kMaxEnergyPasses &&
+  return env_on && (n_groups + kETileFree - 1) / kETileFree + 1 <= kMaxEnergyPasses &&
          n_terms <= 4096;
 }
 
@@ -436,7 +436,7 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
   if (tiled) {
     const int tiles = (int)(dim >> kTileBits);
     const int max_pass = A.max_ops / kTileFree + 2;          // a pass is closed by its (kTileFree + 1)-th independent mask
-    const int e_pass = std::min(kMaxEnergyPasses, (A.ham.n_groups + kTileFree - 1) / kTileFree + 1);
+    const int e_pass = std::min(kMaxEnergyPasses, (A.ham.n_groups + kETileFree - 1) / kETileFree + 1);
     {
       TilePass* tp = (TilePass*)sw.passes; size_t cap = sw.passes_cap;
       SW_TRY(sw_reserve(tp, cap, (size_t)B * max_pass)); sw.passes = tp; sw.passes_cap = cap;
@@ -445,8 +445,8 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
       ChunkRec* cr = (ChunkRec*)sw.chunks; cap = sw.chunks_cap;
       SW_TRY(sw_reserve(cr, cap, (size_t)B * A.max_ops)); sw.chunks = cr; sw.chunks_cap = cap;
       SW_TRY(sw_reserve(sw.csop, sw.csop_cap, (size_t)B * A.max_ops));
-      tp = (TilePass*)sw.epasses; cap = sw.epasses_cap;
-      SW_TRY(sw_reserve(tp, cap, (size_t)B * kMaxEnergyPasses)); sw.epasses = tp; sw.epasses_cap = cap;
+      ETilePass* ep = (ETilePass*)sw.epasses; cap = sw.epasses_cap;
+      SW_TRY(sw_reserve(ep, cap, (size_t)B * kMaxEnergyPasses)); sw.epasses = ep; sw.epasses_cap = cap;
     }
     SW_TRY(sw_reserve(sw.npass, sw.npass_cap, (size_t)2 * B));
     SW_TRY(sw_reserve(sw.eorder, sw.eorder_cap, (size_t)2 * B * ng));
@@ -463,7 +463,7 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
       SW_TRY(sw_reserve(et, cap, (size_t)B * nt)); sw.eterm = et; sw.eterm_cap = cap;
       SW_TRY(sw_reserve(sw.ewi, sw.ewi_cap, (size_t)B * nt));
     }
-    const int tiles_rank = tiles / world;
+    const int tiles_rank = (int)(dim >> kETileBits) / world;     // tiles of the Pauli-term reduction in this rank's slice
     const int e_blocks = (tiles_rank + kTilesPerBlock - 1) / kTilesPerBlock;     // k_t_energy: one partial per workgroup
     SW_TRY(sw_reserve(sw.partial, sw.partial_cap, (size_t)B * e_pass * e_blocks));
     if (want_circuit) {
@@ -488,12 +488,12 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
         hipLaunchKernelGGL(k_s_terms, dim3((m + 63) / 64, B), dim3(64), 0, st, A, sw.masks, sw.meta, n_terms,
                            sw.gxp, sw.tzp, sw.tsg);
         hipLaunchKernelGGL(k_t_plan_energy, dim3((B + 63) / 64), dim3(64), 0, st, A, n_terms, sw.gxp, sw.tzp, sw.tsg,
-                           (TilePass*)sw.epasses, sw.npass + B, sw.eorder, sw.gcx, sw.grec, (TermRec*)sw.trec,
+                           (ETilePass*)sw.epasses, sw.npass + B, sw.eorder, sw.gcx, sw.grec, (TermRec*)sw.trec,
                            sw.eorder + (size_t)B * ng, (EGroupRec*)sw.egrp, (ETermRec*)sw.eterm, sw.ewi);
         sw.plan_energy_ok = !noisy && sw.plan_ops_ok;
       }
       hipLaunchKernelGGL(k_t_energy, dim3((unsigned)e_blocks, B, e_pass), dim3(kThreads), 0, st, A, sw.states, n_terms,
-                         (const TilePass*)sw.epasses, sw.npass + B, (const EGroupRec*)sw.egrp, (const ETermRec*)sw.eterm,
+                         (const ETilePass*)sw.epasses, sw.npass + B, (const EGroupRec*)sw.egrp, (const ETermRec*)sw.eterm,
                          sw.ewi, sw.partial, tiles_rank);
       hipLaunchKernelGGL(k_s_reduce, dim3(B), dim3(kThreads), 0, st, sw.partial, e_pass * e_blocks, A.fout, A.noise,
                          eval_id, A.amp_rank == 0 ? 1 : 0);

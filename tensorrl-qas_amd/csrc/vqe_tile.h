@@ -34,6 +34,16 @@ constexpr int kTileLow = 4;
 constexpr int kTileAmps = 1 << kTileBits;
 constexpr int kTileFree = kTileBits - kTileLow;   // independent masks a pass can take
 constexpr int kMaxEnergyPasses = 32;
+// The Pauli-term reduction uses its own, larger tiles: it only reads the state, so a pass costs it one sweep
+// where a circuit pass costs two, and it is bound by the instructions per amplitude and group, which 16
+// amplitudes per thread halve; 2^12 amplitudes = 64 KiB, two workgroups per CU, 8 independent masks per pass
+// (20-qubit Heisenberg chain: 2 passes instead of 3).
+#ifndef VQE_ETILE_BITS
+#define VQE_ETILE_BITS 11
+#endif
+constexpr int kETileBits = VQE_ETILE_BITS;
+constexpr int kETileAmps = 1 << kETileBits;
+constexpr int kETileFree = kETileBits - kTileLow;
 
 struct TilePass {
   uint32_t basis[kTileBits];  // fully reduced (every vector has a pivot = highest bit that no other vector has), ascending pivots:
@@ -41,6 +51,13 @@ struct TilePass {
   uint32_t pivmask;
   int32_t begin, end;         // ops [begin, end) of the stream / entries [begin, end) of its group order
   int32_t rec_begin, rec_count;   // energy passes: the term records of the pass (TermRec, pass order)
+  uint32_t pad;
+};
+struct ETilePass {            // a pass of the Pauli-term reduction (same fields, kETileBits basis vectors)
+  uint32_t basis[kETileBits];
+  uint32_t pivmask;
+  int32_t begin, end;
+  int32_t rec_begin, rec_count;
   uint32_t pad;
 };
 struct OpCoord { uint32_t cx, cz; };   // tile coordinates of an op's pair mask / sign mask
@@ -227,31 +244,32 @@ __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, Ti
 // What k_t_energy reads per group / per term, made once by the planner and fetched with SCALAR loads
 // (everything in them is the same for all threads and all tiles of the pass): every instruction a wave issues -
 // scalar, LDS or vector - costs the SIMD one issue slot, so whatever can be precomputed is.
-struct EGroupRec {            // 8 dwords
+constexpr int kEPairs = kETileAmps / 2 / kThreads;   // pairs per thread of k_t_energy
+struct EGroupRec {            // 4 + kEPairs dwords
   uint32_t cx16;              // tile coordinates of the X mask, as a byte offset (<< 4); 0: the diagonal group
   uint32_t hb;                // highest set bit of the coordinates
   int32_t nt;                 // its terms: the next nt records of eterm (groups and terms are stored in the order they run)
   uint32_t im;                // some weight has an imaginary part (then wi[] is read as well)
-  uint32_t u16[4];            // byte offset of pair k of a thread: insert0(k * kThreads, hb) << 4
+  uint32_t u16[kEPairs];      // byte offset of pair k of a thread: insert0(k * kThreads, hb) << 4
 };
-struct ETermRec {             // 12 dwords
+struct ETermRec {             // 4 + 2 kEPairs dwords
   double wr;                  // real part of the weight (pair groups: times 2, the p <-> p ^ x symmetry)
   uint32_t cz, tz;            // sign selector in tile coordinates / physical Z mask (sign of the tile origin)
-  double sg[4];               // +-1: parity of cz with the k-th pair of a thread (pair groups)
+  double sg[kEPairs];         // +-1: parity of cz with the k-th pair of a thread (pair groups)
 };
 __global__ void k_t_plan_energy(BatchArgs A, int n_terms, const uint32_t* gxp, const uint32_t* tzp, const double* tsg,
-                                TilePass* passes, int32_t* npass, int32_t* order, uint32_t* gcx, int32_t* grec,
+                                ETilePass* passes, int32_t* npass, int32_t* order, uint32_t* gcx, int32_t* grec,
                                 TermRec* trec, int32_t* gpass, EGroupRec* egrp, ETermRec* eterm, double* ewi) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= A.batch) return;
   const int ng = A.ham.n_groups;
   const uint32_t* gx = gxp + (size_t)b * ng;
   int32_t* gp = gpass + (size_t)b * ng;
-  TilePass* P = passes + (size_t)b * kMaxEnergyPasses;
+  ETilePass* P = passes + (size_t)b * kMaxEnergyPasses;
   // pass bases live in the output records while they are built (fully reduced at every moment)
   int np = 0;
   int dims[kMaxEnergyPasses];
-  int piv[kMaxEnergyPasses][kTileBits];
+  int piv[kMaxEnergyPasses][kETileBits];
   auto reduce = [&](int k, uint32_t x) {
     for (int i = 0; i < dims[k]; ++i) if ((x >> piv[k][i]) & 1u) x ^= P[k].basis[i];
     return x;
@@ -272,7 +290,7 @@ __global__ void k_t_plan_energy(BatchArgs A, int n_terms, const uint32_t* gxp, c
     for (int k = 0; k < np && dst < 0; ++k) {
       const uint32_t r = reduce(k, x);
       if (!r) dst = k;
-      else if (dims[k] < kTileBits) { add(k, r); dst = k; }
+      else if (dims[k] < kETileBits) { add(k, r); dst = k; }
     }
     if (dst < 0) {
       if (np < kMaxEnergyPasses) { dst = open(); const uint32_t r = reduce(dst, x); if (r) add(dst, r); }
@@ -286,38 +304,47 @@ __global__ void k_t_plan_energy(BatchArgs A, int n_terms, const uint32_t* gxp, c
   TermRec* rec = trec + (size_t)b * n_terms;
   int pos = 0, rpos = 0;
   for (int k = 0; k < np; ++k) {
-    for (int q = kTileLow; q < A.n && dims[k] < kTileBits; ++q) { const uint32_t r = reduce(k, 1u << q); if (r) add(k, r); }
-    for (int i = 1; i < kTileBits; ++i)
+    for (int q = kTileLow; q < A.n && dims[k] < kETileBits; ++q) { const uint32_t r = reduce(k, 1u << q); if (r) add(k, r); }
+    for (int i = 1; i < kETileBits; ++i)
       for (int j = i; j > 0 && piv[k][j - 1] > piv[k][j]; --j) {
         const uint32_t tv = P[k].basis[j]; P[k].basis[j] = P[k].basis[j - 1]; P[k].basis[j - 1] = tv;
         const int tp = piv[k][j]; piv[k][j] = piv[k][j - 1]; piv[k][j - 1] = tp;
       }
     uint32_t pm = 0;
-    for (int i = 0; i < kTileBits; ++i) pm |= 1u << piv[k][i];
+    for (int i = 0; i < kETileBits; ++i) pm |= 1u << piv[k][i];
     P[k].pivmask = pm; P[k].begin = pos; P[k].rec_begin = rpos; P[k].pad = 0;
     for (int g = 0; g < ng; ++g)
       if (gp[g] == k) {
         uint32_t c = 0;
-        for (int i = 0; i < kTileBits; ++i) c |= ((gx[g] >> piv[k][i]) & 1u) << i;
+        for (int i = 0; i < kETileBits; ++i) c |= ((gx[g] >> piv[k][i]) & 1u) << i;
         gcx[(size_t)b * ng + g] = c;
         grec[(size_t)b * ng + g] = rpos - P[k].rec_begin;
         const int hb = c ? 31 - __clz((int)c) : 0;
         EGroupRec G;
         G.cx16 = c << 4; G.hb = (uint32_t)hb; G.nt = A.ham.term_off[g + 1] - A.ham.term_off[g]; G.im = 0u;
-        for (int j = 0; j < 4; ++j) G.u16[j] = c ? insert0((uint32_t)j * kThreads, hb) << 4 : 0u;
-        for (int t = A.ham.term_off[g]; t < A.ham.term_off[g + 1]; ++t) {
-          const uint32_t z = tzp[(size_t)b * n_terms + t];
-          uint32_t cz = 0;
-          for (int i = 0; i < kTileBits; ++i) cz |= (uint32_t)parity32(P[k].basis[i] & z) << i;
-          const double sg = tsg[(size_t)b * n_terms + t];
-          const double wr = sg * A.ham.term_cr[t], wi = sg * A.ham.term_ci[t];
-          ETermRec E;
-          E.wr = c ? 2.0 * wr : wr; E.cz = cz; E.tz = z;
-          for (int j = 0; j < 4; ++j) E.sg[j] = parity32(insert0((uint32_t)j * kThreads, hb) & cz) ? -1.0 : 1.0;
-          if (wi != 0.0) G.im = 1u;
-          eterm[(size_t)b * n_terms + rpos] = E;
-          ewi[(size_t)b * n_terms + rpos] = c ? 2.0 * wi : wi;
-          rec[rpos++] = TermRec{wr, wi, z, cz};
+        for (int j = 0; j < kEPairs; ++j) G.u16[j] = c ? insert0((uint32_t)j * kThreads, hb) << 4 : 0u;
+        // the diagonal group's terms go out class by class (class = the bits of cz that the thread's elements
+        // differ in): the kernel sums every class once and combines the classes by a Walsh-Hadamard butterfly
+        constexpr int kClsBits = kETileBits - 8, kCls = 1 << kClsBits;
+        for (int cls = 0; cls < (c ? 1 : kCls); ++cls) {
+          int in_class = 0;
+          for (int t = A.ham.term_off[g]; t < A.ham.term_off[g + 1]; ++t) {
+            const uint32_t z = tzp[(size_t)b * n_terms + t];
+            uint32_t cz = 0;
+            for (int i = 0; i < kETileBits; ++i) cz |= (uint32_t)parity32(P[k].basis[i] & z) << i;
+            if (!c && (int)(cz >> 8) != cls) continue;
+            const double sg = tsg[(size_t)b * n_terms + t];
+            const double wr = sg * A.ham.term_cr[t], wi = sg * A.ham.term_ci[t];
+            ETermRec E;
+            E.wr = c ? 2.0 * wr : wr; E.cz = cz; E.tz = z;
+            for (int j = 0; j < kEPairs; ++j) E.sg[j] = parity32(insert0((uint32_t)j * kThreads, hb) & cz) ? -1.0 : 1.0;
+            if (wi != 0.0) G.im = 1u;
+            eterm[(size_t)b * n_terms + rpos] = E;
+            ewi[(size_t)b * n_terms + rpos] = c ? 2.0 * wi : wi;
+            rec[rpos++] = TermRec{wr, wi, z, cz};
+            ++in_class;
+          }
+          if (!c) G.u16[cls >> 1] |= (uint32_t)in_class << (16 * (cls & 1));     // (u16 is zero for the diagonal group)
         }
         egrp[(size_t)b * ng + pos] = G;
         ord[pos++] = g;
@@ -337,16 +364,18 @@ __device__ __forceinline__ uint32_t tile_origin(uint32_t tile, uint32_t pivmask,
   return p;
 }
 // offset of tile element t = tid + 256 k: low kTileLow bits are address bits, the other 8 coordinates select basis vectors
-__device__ __forceinline__ uint32_t tile_lane_offset(const uint32_t (&basis)[kTileBits], uint32_t tid) {
+template <int BITS>
+__device__ __forceinline__ uint32_t tile_lane_offset(const uint32_t (&basis)[BITS], uint32_t tid) {
   uint32_t x = tid & ((1u << kTileLow) - 1u);
 #pragma unroll
   for (int i = 0; i < 4; ++i) if ((tid >> (kTileLow + i)) & 1u) x ^= basis[kTileLow + i];
   return x;
 }
-__device__ __forceinline__ uint32_t tile_k_offset(const uint32_t (&basis)[kTileBits], int k) {
+template <int BITS>
+__device__ __forceinline__ uint32_t tile_k_offset(const uint32_t (&basis)[BITS], int k) {
   uint32_t x = 0;
 #pragma unroll
-  for (int i = 0; i < kTileBits - kTileLow - 4; ++i) if ((k >> i) & 1) x ^= basis[kTileLow + 4 + i];
+  for (int i = 0; i < BITS - kTileLow - 4; ++i) if ((k >> i) & 1) x ^= basis[kTileLow + 4 + i];
   return x;
 }
 
@@ -519,11 +548,11 @@ __global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states
 #define VQE_TILES_PER_BLOCK 4
 #endif
 constexpr int kTilesPerBlock = VQE_TILES_PER_BLOCK;   // tiles a workgroup of k_t_energy walks through (the next one in flight while it computes)
-__global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double2* states, int n_terms, const TilePass* passes,
+__global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double2* states, int n_terms, const ETilePass* passes,
                                                        const int32_t* npass, const EGroupRec* __restrict__ egrp,
                                                        const ETermRec* __restrict__ eterm, const double* __restrict__ ewi,
                                                        double* partial, int tiles_rank) {
-  __shared__ double2 tile[kTileAmps];
+  __shared__ double2 tile[kETileAmps];
   double* red = (double*)tile;      // reused for the block reduction after the last read of the tile
   const int b = blockIdx.y, pass = blockIdx.z;
   const size_t slot = ((size_t)b * gridDim.z + pass) * gridDim.x + blockIdx.x;
@@ -531,18 +560,18 @@ __global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double
     if (threadIdx.x == 0) partial[slot] = 0.0;
     return;
   }
-  const TilePass P = passes[(size_t)b * kMaxEnergyPasses + pass];
-  uint32_t basis[kTileBits];
+  const ETilePass P = passes[(size_t)b * kMaxEnergyPasses + pass];
+  uint32_t basis[kETileBits];
 #pragma unroll
-  for (int i = 0; i < kTileBits; ++i) basis[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.basis[i]);
+  for (int i = 0; i < kETileBits; ++i) basis[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.basis[i]);
   const uint32_t pivmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.pivmask);
   const size_t dim = (size_t)1 << A.n;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane_off = tile_lane_offset(basis, tid);
   const double2* psi = states + (size_t)b * dim;
-  constexpr int NE = kTileAmps / kThreads;           // elements per thread
-  constexpr int NPR = kTileAmps / 2 / kThreads;      // pairs per thread
-  static_assert(NPR <= 4, "ETermRec::sg holds four signs");
+  constexpr int NE = kETileAmps / kThreads;           // elements per thread
+  constexpr int NPR = kEPairs;      // pairs per thread
+  constexpr int kBlobTerms = NPR <= 4 ? 2 : 1;   // term records requested one group ahead (scalar registers: 102 in all)
   // this workgroup's tiles: blockIdx.x, blockIdx.x + gridDim.x, ... of this rank's slice.  Neighbouring tiles
   // share their DRAM pages (a tile is 128 runs of 256 B spread over the state): workgroups that run side by side
   // take neighbouring tiles, as a one-tile-per-workgroup grid does
@@ -560,11 +589,11 @@ __global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double
   double acc = 0.0;
   // One group: its record and its first two term records are in scalar registers already (requested one group
   // ahead: a scalar load that misses its cache takes ~600 cycles, as long as the whole group)
-  struct Blob { EGroupRec g; ETermRec t0, t1; };
+  struct Blob { EGroupRec g; ETermRec t[kBlobTerms]; };
   auto fetch = [&](Blob& B, int gi, int cur) {
     B.g = G[gi < n_in_pass ? gi : n_in_pass - 1];
-    B.t0 = T[cur < r_count ? cur : 0];
-    B.t1 = T[cur + 1 < r_count ? cur + 1 : 0];
+#pragma unroll
+    for (int i = 0; i < kBlobTerms; ++i) B.t[i] = T[cur + i < r_count ? cur + i : 0];
   };
   for (int tl = t_first; tl < t_last; tl += t_step) {
     if (tl != t_first) __syncthreads();                 // the previous tile has been read to the end
@@ -590,15 +619,22 @@ __global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double
         double2 a[NE];
 #pragma unroll
         for (int k = 0; k < NE; ++k) a[k] = tile[tid + (uint32_t)k * kThreads];
+        // D_k = sum_t v_t (-1)^{parity(k & class_t)}: one sum per class (terms stored class by class, counts in
+        // u16), then the butterfly over the classes - per term one signed add instead of NE
         double d[NE];
+        int tc = cur;
 #pragma unroll
-        for (int k = 0; k < NE; ++k) d[k] = 0.0;
-        for (int t = 0; t < nt; ++t) {
-          const uint32_t cz = T[cur + t].cz;
-          const double v = signed_w(T[cur + t].wr, tid, cz, T[cur + t].tz);
-#pragma unroll
-          for (int k = 0; k < NE; ++k) d[k] += (__builtin_popcount(((uint32_t)k * kThreads) & cz) & 1) ? -v : v;
+        for (int cls = 0; cls < NE; ++cls) {
+          const int n_cls = (int)((B.g.u16[cls >> 1] >> (16 * (cls & 1))) & 0xffffu);
+          double sum = 0.0;
+          for (int t = 0; t < n_cls; ++t, ++tc) sum += signed_w(T[tc].wr, tid, T[tc].cz, T[tc].tz);
+          d[cls] = sum;
         }
+#pragma unroll
+        for (int h = 1; h < NE; h <<= 1)
+#pragma unroll
+          for (int i = 0; i < NE; ++i)
+            if (!(i & h)) { const double x = d[i], y = d[i | h]; d[i] = x + y; d[i | h] = x - y; }
 #pragma unroll
         for (int k = 0; k < NE; ++k) acc = fma(a[k].x * a[k].x + a[k].y * a[k].y, d[k], acc);
         return;
@@ -621,9 +657,9 @@ __global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double
 #pragma unroll
         for (int k = 0; k < NPR; ++k) dr[k] = fma(r.sg[k], v, dr[k]);
       };
-      if (nt > 0) term(B.t0);
-      if (nt > 1) term(B.t1);
-      for (int t = 2; t < nt; ++t) term(T[cur + t]);
+#pragma unroll
+      for (int i = 0; i < kBlobTerms; ++i) if (nt > i) term(B.t[i]);
+      for (int t = kBlobTerms; t < nt; ++t) term(T[cur + t]);
 #pragma unroll
       for (int k = 0; k < NPR; ++k) acc = fma(pa[k].x * pb[k].x + pa[k].y * pb[k].y, dr[k], acc);
       if (B.g.im) {            // imaginary parts of the weights (odd number of Y factors): rare
