@@ -65,13 +65,17 @@ constexpr int kTileK = kTileBits - 8;   // ops applied per LDS round trip: 256 t
 // One chunk of kTileK ops as k_t_ops wants it (made once by the planner, read with scalar loads): slot j of the
 // thread's coset basis is the partner mask of op j when that is independent of the earlier slots, else a filler
 // unit vector (the bookkeeping of k_s_opk, in tile coordinates).
-struct ChunkRec {             // 16 dwords, indexed by the chunk's first op
+// A chunk holds up to kTileK pair ops (RX / RY: each needs a slot) and the diagonal ops (RZ, Pauli-Z) between
+// them, which act on whatever elements a thread holds: kChunkOps ops at most.
+constexpr int kChunkOps = 6;
+struct ChunkRec {             // 24 dwords, indexed by the chunk's first op
   uint32_t g16[3];            // slot masks as byte offsets (<< 4)
   uint32_t pvc;               // pivot positions of the reduced slot basis, ascending, 5 bits each | number of ops << 16
   struct {
     uint32_t kfe;             // kind | flip code << 4 (partner of element e: e ^ flip) | inversion << 8 | ebits << 16
     uint32_t cz, zm;          // sign selector in tile coordinates / the op's physical Z mask (sign of the tile origin)
-  } op[4];                    // ebits: bit e = parity(cz & combination e of the slot masks)
+  } op[kChunkOps];            // ebits: bit e = parity(cz & combination e of the slot masks)
+  uint32_t pad[2];
 };
 struct TermRec { double wr, wi; uint32_t tz, cz; };   // coefficient (incl. (-1)^{z.c}), physical Z mask, its tile coordinates
 
@@ -124,7 +128,7 @@ struct TileBasis {
 };
 
 // ops of every stream -> passes + tile coordinates.  passes: [batch][max_pass]; opc: [batch][max_ops]
-static_assert(sizeof(ChunkRec) == 64 && kTileK <= 3, "ChunkRec: three slots, sixteen dwords");
+static_assert(sizeof(ChunkRec) == 96 && kTileK <= 3, "ChunkRec: three slots, 24 dwords");
 __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, TilePass* passes, OpCoord* opc,
                              ChunkRec* chunks, int32_t* npass, int max_pass) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,13 +138,15 @@ __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, Ti
   OpCoord* oc = opc + (size_t)b * A.max_ops;
   ChunkRec* ck = chunks + (size_t)b * A.max_ops;
   constexpr int K = kTileK, E = 1 << K;
-  // the coset bookkeeping of k_s_opk for the ops [o, o + cnt) of a pass, in tile coordinates
-  auto plan_chunk = [&](int o, int cnt) {
+  // The coset bookkeeping of k_s_opk in tile coordinates for the chunk that starts at op o of a pass ending at
+  // `end`: pair ops take the slots in order while their masks are independent of the slots so far (a dependent
+  // mask gets its flip code), diagonal ops ride along; returns the number of ops taken.
+  auto plan_chunk = [&](int o, int end) {
     uint32_t g[4] = {0u, 0u, 0u, 0u}, red[4] = {0u, 0u, 0u, 0u};
-    int hbit[4] = {0, 0, 0, 0}, flip[4] = {0, 0, 0, 0};
-    bool own[4] = {false, false, false, false};
+    int hbit[4] = {0, 0, 0, 0};
+    int slot_of[kChunkOps];
     uint32_t pivots = 0;
-    int nred = 0;
+    int nred = 0, nslots = 0, cnt = 0;
     auto reduce = [&](uint32_t x) {
       for (int i = 0; i < nred; ++i) if ((x >> hbit[i]) & 1u) x ^= red[i];
       return x;
@@ -152,33 +158,26 @@ __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, Ti
       pivots |= 1u << h;
       ++nred;
     };
-    for (int j = 0; j < K; ++j)
-      if (j < cnt) {
-        const int kd = op[o + j].kind & 0xff;
-        if (kd == OP_RX || kd == OP_RY) {
-          const uint32_t r = reduce(oc[o + j].cx);
-          if (r) { push(r); g[j] = oc[o + j].cx; own[j] = true; flip[j] = 1 << j; }
+    while (o + cnt < end && cnt < kChunkOps) {
+      const int kd = op[o + cnt].kind & 0xff;
+      slot_of[cnt] = -1;
+      if (kd == OP_RX || kd == OP_RY) {
+        const uint32_t r = reduce(oc[o + cnt].cx);
+        if (r) {
+          if (nslots == K) break;              // a fourth independent mask: the next chunk
+          push(r); g[nslots] = oc[o + cnt].cx; slot_of[cnt] = nslots; ++nslots;
         }
       }
+      ++cnt;
+    }
     int q = 0;
-    for (int j = 0; j < K; ++j)
-      if (!own[j]) {
-        uint32_t r = 0;
-        while ((r = reduce(1u << q)) == 0) ++q;
-        push(r);
-        g[j] = 1u << q;
-        ++q;
-      }
-    for (int j = 0; j < K; ++j)
-      if (j < cnt && !own[j]) {
-        const int kd = op[o + j].kind & 0xff;
-        if (kd == OP_RX || kd == OP_RY)
-          for (int f = 1; f < E; ++f) {
-            uint32_t x = 0;
-            for (int i = 0; i < K; ++i) if ((f >> i) & 1) x ^= g[i];
-            if (x == oc[o + j].cx) flip[j] = f;
-          }
-      }
+    for (int j = nslots; j < K; ++j) {         // fillers for the unused slots
+      uint32_t r = 0;
+      while ((r = reduce(1u << q)) == 0) ++q;
+      push(r);
+      g[j] = 1u << q;
+      ++q;
+    }
     ChunkRec c;
     for (int j = 0; j < 3; ++j) c.g16[j] = g[j] << 4;
     uint32_t pvc = (uint32_t)cnt << 16;
@@ -187,9 +186,21 @@ __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, Ti
       for (int qb = 0; qb < kTileBits; ++qb) if ((pivots >> qb) & 1u) { pvc |= (uint32_t)qb << (5 * k); ++k; }
     }
     c.pvc = pvc;
-    for (int j = 0; j < 4; ++j) {
+    c.pad[0] = c.pad[1] = 0u;
+    for (int j = 0; j < kChunkOps; ++j) {
       c.op[j].kfe = OP_NOP; c.op[j].cz = 0u; c.op[j].zm = 0u;
       if (j < cnt) {
+        const int kd = op[o + j].kind & 0xff;
+        int flip = 0;
+        if (kd == OP_RX || kd == OP_RY) {
+          if (slot_of[j] >= 0) flip = 1 << slot_of[j];
+          else
+            for (int f = 1; f < E; ++f) {
+              uint32_t x = 0;
+              for (int i = 0; i < K; ++i) if ((f >> i) & 1) x ^= g[i];
+              if (x == oc[o + j].cx) flip = f;
+            }
+        }
         const uint32_t cz = oc[o + j].cz;
         uint32_t ebits = 0;
         for (int e = 0; e < E; ++e) {
@@ -197,13 +208,13 @@ __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, Ti
           for (int i = 0; i < K; ++i) if ((e >> i) & 1) x ^= g[i];
           ebits |= (uint32_t)parity32(x & cz) << e;
         }
-        c.op[j].kfe = (uint32_t)(op[o + j].kind & 0xf) | ((uint32_t)flip[j] << 4) | ((uint32_t)((op[o + j].kind >> 8) & 1) << 8) |
-                      (ebits << 16);
+        c.op[j].kfe = (uint32_t)(kd & 0xf) | ((uint32_t)flip << 4) | ((uint32_t)((op[o + j].kind >> 8) & 1) << 8) | (ebits << 16);
         c.op[j].cz = cz;
         c.op[j].zm = op[o + j].zm;
       }
     }
     ck[o] = c;
+    return cnt;
   };
   TilePass* P = passes + (size_t)b * max_pass;
   TileBasis B;
@@ -219,7 +230,7 @@ __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, Ti
         oc[o].cx = (kd == OP_RX || kd == OP_RY) ? B.coords(op[o].xm) : 0u;
         oc[o].cz = B.zcoords(op[o].zm);
       }
-      for (int o = begin; o < end; o += K) plan_chunk(o, end - o < K ? end - o : K);
+      for (int o = begin; o < end;) o += plan_chunk(o, end);
     }
     ++np;
   };
@@ -470,10 +481,10 @@ __global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states
       p0 = tile_origin((uint32_t)(tl + t_step), pivmask, A.n);
       stage.load([&](int k) { return src[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
     }
-    for (int o = o_begin; o < o_end; o += K) {
+    for (int o = o_begin, cnt = 0; o < o_end; o += cnt) {
       const ChunkRec& cr = CH[o];
       const uint32_t pvc = cr.pvc;
-      const int cnt = (int)(pvc >> 16);
+      cnt = (int)(pvc >> 16);
       // the thread's coset: zeros inserted into tid at the pivot positions, then the 2^K combinations of the slot masks
       uint32_t t0 = tid;
 #pragma unroll
@@ -489,9 +500,8 @@ __global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states
         off[e] = a0 ^ x;
         v[e] = lds_load_d2(tile_rb, off[e]);
       }
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        if (j >= cnt) break;
+#pragma unroll 1
+      for (int j = 0; j < cnt; ++j) {
         const uint32_t kfe = cr.op[j].kfe;
         const int kind = (int)(kfe & 0xfu), flip = (int)((kfe >> 4) & 0xfu);
         const uint32_t ebits = kfe >> 16;
