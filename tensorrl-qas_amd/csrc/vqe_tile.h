@@ -15,13 +15,16 @@
 //     coordinates of a mask are just its bits at the pivot positions, and the sign selector parity(p & z)
 //     of a rotation / Pauli term splits into parity(p0 & z) (per tile, scalar) ^ parity(t & cz) with
 //     cz_i = parity(basis_i & z);
-//   * inside a tile three ops at a time are applied from registers (the coset trick of k_s_opk, in tile
-//     coordinates: 256 threads x 8 amplitudes), so LDS sees one read + one write of the tile per three ops;
+//   * inside a tile a chunk of up to three pair ops and the diagonal ops between them is applied from registers
+//     (the coset trick of k_s_opk, in tile coordinates: 256 threads x 8 amplitudes), so LDS sees one read + one
+//     write of the tile per chunk;
 //   * the first pass of a stream reads the shared initial state instead of its own buffer (no separate
-//     initialisation sweep).
-// Every floating-point update is the per-element form of s_apply_k (vqe_stream.h), so states and
-// energies are bit-identical to the one-sweep-per-four-ops kernels these replace up to the order in
-// which the energy partials are summed.
+//     initialisation sweep);
+//   * a workgroup walks several tiles with the next one already in flight, and everything a kernel needs per
+//     chunk / group / term comes precomputed from the planner by scalar loads: a SIMD issues one instruction per
+//     4-5 cycles whatever its kind, so the instruction count per amplitude is what these kernels are written for
+//     (DESIGN.md 4.3).
+// Every floating-point update of the circuit is the per-element form of s_apply_k (vqe_stream.h).
 #pragma once
 
 namespace vqe {
