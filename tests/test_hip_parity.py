@@ -216,6 +216,58 @@ def test_streaming_path(tq, n, G, seed):
         assert abs(got[i] - vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, ths[i]), *ham)) < E_TOL
 
 
+def test_streaming_groups_with_many_terms(tq):
+    """Tile kernels: X-mask groups with more terms than the two whose records k_t_energy requests ahead, complex
+    weights (the imaginary sign sums), a diagonal group that fills several sign classes, a circuit long enough
+    for several passes and chunks with diagonal ops riding along."""
+    n = 15
+    rng = np.random.default_rng(1515)
+    psi0 = random_state(n, rng)
+    xs, zs, cs = [], [], []
+    for x in (0, 0b11, 0b101000000000011, 0b110000, 1 << 14):
+        for _ in range(9):
+            z = int(rng.integers(0, 1 << n))
+            if bin(x & z).count("1") % 2:          # keep every term Hermitian on its own: even number of Y factors
+                z ^= (x & -x) if x else 0
+            xs.append(x); zs.append(z); cs.append(float(rng.normal()))
+    ham = (np.array(xs, np.uint64), np.array(zs, np.uint64), np.array(cs))
+    kind, q0, q1, pidx, th = random_gates(n, 60, rng)
+    eng = _engine(tq, n, psi0, ham)
+    eng.set_circuit(tq.Circuit(kind, q0, q1, pidx, th.size))
+    psi = vo.run_circuit(psi0, kind, q0, q1, pidx, th)
+    assert np.abs(eng.get_state(th) - psi).max() < A_TOL
+    assert abs(eng.energy(th) - vo.energy_pauli(psi, *ham)) < E_TOL
+    ham_c = random_hamiltonian(n, 60, rng, real=False)          # odd Y counts: imaginary tables
+    eng.set_hamiltonian(*ham_c)
+    assert abs(eng.energy(th) - vo.energy_pauli(psi, *ham_c)) < E_TOL
+
+
+def test_streaming_fallback_kernels(tq, tmp_path):
+    """VQE_STREAM_TILED=0 (read once per process) selects the one-sweep-per-four-ops kernels that also serve
+    Hamiltonian shards too large for the tile planner: same energies as the oracle."""
+    import subprocess, sys, os, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fallback.py"
+    script.write_text(
+        "import sys, json, numpy as np\n"
+        "sys.path[:0] = %r\n"
+        "import tensorrl_qas_amd as tq, vqe_oracle as vo\n"
+        "from helpers import random_gates, random_hamiltonian, random_state\n"
+        "n = 14; rng = np.random.default_rng(1414)\n"
+        "psi0 = random_state(n, rng); ham = random_hamiltonian(n, 25, rng, real=False)\n"
+        "kind, q0, q1, pidx, th = random_gates(n, 20, rng)\n"
+        "eng = tq.VQEEngine(n); eng.set_init_state(psi0); eng.set_hamiltonian(*ham)\n"
+        "eng.set_circuit(tq.Circuit(kind, q0, q1, pidx, th.size))\n"
+        "psi = vo.run_circuit(psi0, kind, q0, q1, pidx, th)\n"
+        "print(json.dumps({'e': eng.energy(th), 'ref': vo.energy_pauli(psi, *ham),\n"
+        "                  'da': float(np.abs(eng.get_state(th) - psi).max())}))\n" % ([root, os.path.join(root, "oracle"), os.path.join(root, "tests")],))
+    env = dict(os.environ, VQE_STREAM_TILED="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert abs(out["e"] - out["ref"]) < E_TOL and out["da"] < A_TOL
+
+
 def test_term_sharding_sums_to_full(tq):
     for n in (12, 14):
         rng = np.random.default_rng(n)
