@@ -431,18 +431,20 @@ __device__ __forceinline__ double t_flip(double s, uint32_t flipword) {
   return __hiloint2double(__double2hiint(s) ^ (int)(flipword & 0x80000000u), __double2loint(s));
 }
 // w[e] = c v[e] + s(e) v[e ^ F]: the per-element updates of s_apply_k (vqe_stream.h), same expressions
-template <int E, int F>
-__device__ __forceinline__ void t_rot_pairs(const double2 (&v)[E], double2 (&w)[E], bool rx, double c, double s, uint32_t fw,
-                                            uint32_t ebits) {
+template <int E, int F, bool RX>
+__device__ __forceinline__ void t_rot_pairs(double2 (&v)[E], double c, double s, uint32_t fw, uint32_t ebits) {
+  double2 w[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const double2 a = v[e], bq = v[e ^ F];
-    if (rx) w[e] = make_double2(c * a.x - s * bq.y, c * a.y + s * bq.x);
+    if (RX) w[e] = make_double2(c * a.x - s * bq.y, c * a.y + s * bq.x);
     else {
       const double sg = t_flip(s, fw ^ (ebits << (31 - e)));
       w[e] = make_double2(c * a.x + sg * bq.x, c * a.y + sg * bq.y);
     }
   }
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = w[e];
 }
 
 __global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states, const ChunkRec* __restrict__ chunks,
@@ -512,20 +514,26 @@ __global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states
         // sign of element e: parity(t0 & cz) [vector] ^ ebits[e] ^ parity(tile origin & zm) ^ inversion [scalars]
         const uint32_t fw = ((uint32_t)__builtin_popcount(t0 & cr.op[j].cz) +
                              ((uint32_t)__builtin_popcount(pt & cr.op[j].zm) ^ ((kfe >> 8) & 1u))) << 31;
-        if (kind == OP_RX || kind == OP_RY) {
-          double2 w[E];
-          const bool rx = kind == OP_RX;
+        if (kind == OP_RX) {
           switch (flip) {
-            case 1: t_rot_pairs<E, 1>(v, w, rx, c.x, c.y, fw, ebits); break;
-            case 2: t_rot_pairs<E, 2>(v, w, rx, c.x, c.y, fw, ebits); break;
-            case 3: t_rot_pairs<E, 3>(v, w, rx, c.x, c.y, fw, ebits); break;
-            case 4: t_rot_pairs<E, 4>(v, w, rx, c.x, c.y, fw, ebits); break;
-            case 5: t_rot_pairs<E, 5>(v, w, rx, c.x, c.y, fw, ebits); break;
-            case 6: t_rot_pairs<E, 6>(v, w, rx, c.x, c.y, fw, ebits); break;
-            default: t_rot_pairs<E, 7>(v, w, rx, c.x, c.y, fw, ebits); break;
+            case 1: t_rot_pairs<E, 1, true>(v, c.x, c.y, fw, ebits); break;
+            case 2: t_rot_pairs<E, 2, true>(v, c.x, c.y, fw, ebits); break;
+            case 3: t_rot_pairs<E, 3, true>(v, c.x, c.y, fw, ebits); break;
+            case 4: t_rot_pairs<E, 4, true>(v, c.x, c.y, fw, ebits); break;
+            case 5: t_rot_pairs<E, 5, true>(v, c.x, c.y, fw, ebits); break;
+            case 6: t_rot_pairs<E, 6, true>(v, c.x, c.y, fw, ebits); break;
+            default: t_rot_pairs<E, 7, true>(v, c.x, c.y, fw, ebits); break;
           }
-#pragma unroll
-          for (int e = 0; e < E; ++e) v[e] = w[e];
+        } else if (kind == OP_RY) {
+          switch (flip) {
+            case 1: t_rot_pairs<E, 1, false>(v, c.x, c.y, fw, ebits); break;
+            case 2: t_rot_pairs<E, 2, false>(v, c.x, c.y, fw, ebits); break;
+            case 3: t_rot_pairs<E, 3, false>(v, c.x, c.y, fw, ebits); break;
+            case 4: t_rot_pairs<E, 4, false>(v, c.x, c.y, fw, ebits); break;
+            case 5: t_rot_pairs<E, 5, false>(v, c.x, c.y, fw, ebits); break;
+            case 6: t_rot_pairs<E, 6, false>(v, c.x, c.y, fw, ebits); break;
+            default: t_rot_pairs<E, 7, false>(v, c.x, c.y, fw, ebits); break;
+          }
         } else if (kind == OP_RZ) {
 #pragma unroll
           for (int e = 0; e < E; ++e) {
