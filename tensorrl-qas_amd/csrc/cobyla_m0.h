@@ -13,7 +13,7 @@
 // functions by linear interpolation", 1994) and shipped by scipy <= 1.15 as cobyla2.f.  The
 // sequence of simplex operations, acceptance tests and the order of floating-point
 // accumulations follow that publication so that iterates agree with scipy's to rounding
-// (tests/test_cobyla.py pins this against recorded scipy 1.15.3 traces).
+// (tests/test_abi.py::test_host_cobyla_reproduces_scipy_traces pins this against recorded scipy 1.15.3 traces).
 //
 // With m = 0 the trust-region LP has the closed form dx = rho * a / |a| (a = minus the
 // model gradient); trstlp_m0() evaluates it with the same Givens accumulation the general
