@@ -460,6 +460,35 @@ def g_sweep(tq, eng, n, B, maxfun, rank):
     return out
 
 
+def noisy_aux(tq, n, ham, psi0, batch, B, G, maxfun):
+    """BASELINE config 5 at bench size: the same circuits with a depolarising channel behind every gate
+    (p1 = 0.01, p2 = 0.05; reference environments/VQAs/VQE_qulacs_TN_notin_RL_noise.py:13-54), one Pauli
+    trajectory per evaluation, fused env-step kernel.  A noisy objective ends COBYLA early, so env-steps/s
+    and evaluations/s are both given."""
+    k = batch["kind"].reshape(B, G); q0 = batch["q0"].reshape(B, G); q1 = batch["q1"].reshape(B, G)
+    p = batch["pidx"].reshape(B, G)
+    k2 = np.empty((B, 2 * G), np.int32); a2 = np.empty_like(k2); b2 = np.empty_like(k2); p2 = np.empty_like(k2)
+    k2[:, 0::2] = k; k2[:, 1::2] = np.where(k == 0, 5, 4)          # DEPOL2 behind a CNOT, DEPOL1 behind a rotation
+    a2[:, 0::2] = q0; a2[:, 1::2] = q0
+    b2[:, 0::2] = q1; b2[:, 1::2] = np.where(k == 0, q1, -1)
+    p2[:, 0::2] = p; p2[:, 1::2] = -1
+    eng = tq.VQEEngine(n)
+    eng.set_init_state(psi0)
+    eng.set_hamiltonian(ham.xmask, ham.zmask, ham.coeff)
+    eng.set_noise(0.01, 0.05, 7)
+    eng.batch_load_flat(np.arange(B + 1, dtype=np.int64) * 2 * G, k2.ravel(), a2.ravel(), b2.ravel(), p2.ravel(),
+                        batch["par_off"], batch["theta"])
+    eng.batch_set_new_gate(np.full(B, 2 * G - 2, np.int32))
+    for _ in range(2):
+        eng.batch_run_env_step(1.0, 1e-4, maxfun)
+        eng.sync()
+    ms = eng.last_kernel_ms()
+    _, f, nfev = eng.batch_fetch(want_x=False)
+    return {"workload": f"lih12_synthetic631_fixed_noise_p1_0.01_p2_0.05_G{G}_B{B}", "env_steps_per_s_per_gpu": B / (ms * 1e-3),
+            "evals_per_s_per_gpu": float(nfev.sum() + B) / (ms * 1e-3), "mean_nfev": float(nfev.mean()), "kernel_ms": ms,
+            "mean_energy": float(np.mean(f)), "noise": "Pauli trajectories, one draw per (environment, evaluation, gate)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -473,6 +502,7 @@ def main():
     ap.add_argument("--no-heis20", action="store_true")
     ap.add_argument("--no-mps2qc", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the G in {8,32,64,110} auxiliary launches")
+    ap.add_argument("--no-noisy", action="store_true", help="skip the fixed_noise (config 5) auxiliary launch")
     ap.add_argument("--no-episode", action="store_true", help="skip the LIH12q fixed config through VecCircuitEnv")
     ap.add_argument("--episode", action="store_true", help="(default at N = 1; kept for older command lines)")
     ap.add_argument("--episode-envs", type=int, default=4096)
@@ -485,7 +515,7 @@ def main():
     ap.add_argument("--selftest-launch", action="store_true", help="CPU rehearsal of the multi-rank launch path (no GPU work)")
     args = ap.parse_args()
     if args.headline_only:
-        args.no_cpu_baseline = args.no_heis20 = args.no_mps2qc = args.no_sweep = args.no_episode = True
+        args.no_cpu_baseline = args.no_heis20 = args.no_mps2qc = args.no_sweep = args.no_episode = args.no_noisy = True
 
     # ---- launch: under torchrun every process is a rank; started plainly with --gpus N > 1 this process
     # spawns the ranks itself, before anything touches the GPU
@@ -580,6 +610,7 @@ def main():
         warm = {"env_steps_per_s_per_gpu": B / (warm_ms * 1e-3), "mean_nfev": float(nfev_w.mean()),
                 "note": "same circuits, x0 = optimum of the previous step (float32), kernel time only"}
     sweep = None if args.no_sweep else g_sweep(tq, eng, n, B, args.maxfun, rank)
+    noisy = None if (args.no_noisy or rank != 0) else noisy_aux(tq, n, ham, psi0, batch, B, G, args.maxfun)
 
     episode = None
     if not args.no_episode and rank == 0 and world == 1:
@@ -621,6 +652,8 @@ def main():
             out["warm_start"] = warm
         if sweep is not None:
             out["gate_sweep"] = sweep
+        if noisy is not None:
+            out["noisy12"] = noisy
         if episode is not None:
             out["episode"] = episode
         if heis is not None:

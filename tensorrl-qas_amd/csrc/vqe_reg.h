@@ -84,7 +84,8 @@ __device__ __forceinline__ uint32_t sign_word(uint32_t svec) {
 // Scheduled record: xm = sign word of the op in its layout (bit r: parity of the op's Z mask
 // with register combination r), or the layout index of a RELAYOUT; kind = op | inv << 8 |
 // partner mask j << 16; pidx = BYTE offset of the op's (cos, sin) in L.cs (0 when it has none):
-// everything a thread would otherwise recompute for every evaluation.
+// everything a thread would otherwise recompute for every evaluation.  Bits 24..31 of kind: number of records
+// behind this one that the run loop may jump over (inactive noise slots; set per evaluation by patch_noise_wave).
 template <int N>
 __device__ __forceinline__ void schedule_ops(const Lds& L) {
   constexpr int R = N - Geo<N>::LT;
@@ -278,6 +279,7 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
   for (int o = 0; o < nops; ++o) {
     const Op op = nxt;
     const double2 cs = ncs;
+    o += (int)((uint32_t)op.kind >> 24);          // inactive noise slots behind this record (an iteration costs ~250 cycles even when it does nothing)
     nxt = L.sched[o + 1];
     ncs = *(const double2*)(cs_b + nxt.pidx);
     const int kind = op.kind & 0xff;
@@ -310,7 +312,7 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
     const int inv = (op.kind >> 8) & 1;
     const uint32_t flip = (uint32_t)(parity32(op.zm & base) ^ inv);
     const uint32_t w = op.xm ^ (0u - flip);
-    const int jm = op.kind >> 16;
+    const int jm = (op.kind >> 16) & 0xff;
     if (kind == OP_RX) {
       VQE_PAIR_SWITCH(jm, rx_pairs, amp, cs.x, cs.y)
     } else if (kind == OP_RY) {
