@@ -516,11 +516,13 @@ __device__ __forceinline__ void patch_noise_wave(const BatchArgs& A, int b, uint
     const uint64_t nkey = noise_key(A.noise.seed, (uint64_t)b, eval_id);
     uint32_t c = 0;
     int ny = 0, kbase = 0;
+    int4 rnext = lane < G ? gsrc[lane] : make_int4(-1, 0, 0, 0);
     for (int base = 0; base < G; base += 64) {
       const int i = base + lane;
       int kind = -1, q0 = 0, q1 = 0, code = 0;
+      const int4 r = rnext;                      // (the records of the next chunk are requested before this one is walked)
+      if (i + 64 < G) rnext = gsrc[i + 64];
       if (i < G && !(i >= skip && i < skip_end)) {
-        const int4 r = gsrc[i];
         kind = r.x; q0 = r.y; q1 = r.z < 0 ? 0 : r.z;
         if (kind == G_DEPOL1 || kind == G_DEPOL2) {
           const double u = noise_uniform_k(nkey, (uint64_t)(i - ((skip >= 0 && i >= skip_end) ? skip_end - skip : 0)));
@@ -543,7 +545,15 @@ __device__ __forceinline__ void patch_noise_wave(const BatchArgs& A, int b, uint
       ny += __popcll(__ballot(pa == 2)) + __popcll(__ballot(pb == 2));
       uint64_t inv0 = 0, inv1 = 0;
       const int cnt = G - base < 64 ? G - base : 64;
-      for (int j = 0; j < cnt; ++j) {
+      // while no X / Y error has happened the offset c is zero, CNOTs keep it zero and every sign bit is clear: the
+      // serial walk starts at the first gate of the chunk that flips a bit (with ~2 errors per evaluation most
+      // chunks are skipped in part or entirely)
+      int j0 = 0;
+      if (c == 0) {
+        const uint64_t flips = __ballot((flip_a | flip_b) != 0u);
+        j0 = flips ? __ffsll((long long)flips) - 1 : cnt;
+      }
+      for (int j = j0; j < cnt; ++j) {
         const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)w1, j);
         const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)w2, j);
         c ^= a & 0xffffu;                                   // X error on q0
@@ -1331,7 +1341,13 @@ struct StagedCobyla {
       if (staged) call<FIRST, CobL>((lds_double*)lmem, f, rhobeg, rhoend, maxfun);
       else call<FIRST, CobG>(gmem, f, rhobeg, rhoend, maxfun);
     } else if (threadIdx.x < 128) {
+#ifdef VQE_STAMPS
+      const long long ts0 = clock64();
+#endif
       side();
+#ifdef VQE_STAMPS
+      if (threadIdx.x == 64 && !FIRST) atomicAdd(&g_cby_dbg[6], (unsigned long long)(clock64() - ts0));   // the side job of wave 1
+#endif
     }
 #ifdef VQE_STAMPS
     const long long t2 = clock64();
