@@ -574,21 +574,21 @@ __device__ __forceinline__ void patch_noise_wave(const BatchArgs& A, int b, uint
       if (nrec >= 1) apply(k0, (int)((inv0 >> lane) & 1ull), kind <= G_RZ ? -1 : pa);
       if (nrec == 2) apply(k0 + 1, (int)((inv1 >> lane) & 1ull), pb);
     }
-    if constexpr (N >= 10) {
+    {
       // jump counts for the run loop: every record learns how many inactive slots follow it (walked from the
       // end in chunks of 64 records, `lead` = inactive records at the head of the chunk behind)
-      const int ns = L.meta[4];
+      const int ns = N >= 10 ? L.meta[4] : kmax;
       int lead = 0;
       for (int base = ((ns - 1) / 64) * 64; base >= 0; base -= 64) {
         const int k = base + lane;
-        const int kd = k < ns ? L.sched[k].kind : 0;
+        const int kd = k < ns ? exe[k].kind : 0;
         const bool nop = k < ns && (kd & 0xff) == OP_NOP;
         const uint64_t m = __ballot(nop);
         const uint64_t behind = lane < 63 ? (m >> (lane + 1)) : 0ull;          // inactivity of the records behind this lane's
         const int in_chunk = 63 - lane;                                          // records behind it inside the chunk
         int run = behind == ~0ull >> (lane + 1) && lane < 63 ? in_chunk : (lane < 63 ? __ffsll((long long)~behind) - 1 : 0);
         if (run >= in_chunk) run = in_chunk + lead;                              // the run reaches the next chunk
-        if (k < ns) L.sched[k].kind = (kd & 0x00ffffff) | ((run < 255 ? run : 255) << 24);
+        if (k < ns) exe[k].kind = (kd & 0x00ffffff) | ((run < 255 ? run : 255) << 24);
         lead = (m == ~0ull) ? 64 + lead : __ffsll((long long)~m) - 1;            // (a short last chunk has zeros beyond ns)
       }
     }
@@ -673,6 +673,7 @@ __device__ __forceinline__ void run_ops(const Lds& L, const double* theta, int P
   const int nops = L.meta[0];
   for (int o = 0; o < nops; ++o) {
     const Op op = L.ops[o];
+    o += (int)((uint32_t)op.kind >> 24);   // inactive noise slots behind this record (jump counts of patch_noise_wave)
     const int kind = op.kind & 0xff;
     if (kind == OP_NOP) continue;   // inactive noise slot: nothing to do, no barrier needed
     const int inv = (op.kind >> 8) & 1;
