@@ -399,14 +399,20 @@ int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
   // register path: the raw ops are staged in the (idle) state region, 2^n records at most
   if (N >= kRegMinQubits && (size_t)A.max_ops > ((size_t)1 << N))
     return fail(h, VQE_EINVAL, "circuit too large for the LDS-resident path (more than 2^n rotations)");
+  // n = 6..9 with more than 64 parameters in a circuit (the trainable regime): the variant whose optimiser update
+  // runs on the whole workgroup (StagedCobyla<N, WIDE>)
+  constexpr bool kHasWide = N >= 6 && N < 10;
+  static const bool wide_on = [] { const char* e = std::getenv("VQE_WIDE_UPDATE"); return !(e && e[0] == '0'); }();   // A/B knob
+  const bool wide = kHasWide && wide_on && which == 1 && A.max_params > 64;
   const void* fn = which == 0 ? (const void*)k_lds_energy<N>
-                   : which == 1 ? (const void*)k_lds_minimize<N>
+                   : which == 1 ? (wide ? (const void*)k_lds_minimize<N, kHasWide> : (const void*)k_lds_minimize<N>)
                                 : (const void*)k_lds_state<N>;
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   h->last_wg_per_cu = std::max(1, std::min(8, (int)(h->lds_per_cu / lds)));
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
   const dim3 grid(which == 2 ? 1 : A.batch), block(Geo<N>::NT);
   if (which == 0) hipLaunchKernelGGL(k_lds_energy<N>, grid, block, lds, h->stream, A);
+  else if (which == 1 && wide) hipLaunchKernelGGL((k_lds_minimize<N, kHasWide>), grid, block, lds, h->stream, A);
   else if (which == 1) hipLaunchKernelGGL(k_lds_minimize<N>, grid, block, lds, h->stream, A);
   else hipLaunchKernelGGL(k_lds_state<N>, grid, block, lds, h->stream, A);
   HIP_TRY(h, hipGetLastError());

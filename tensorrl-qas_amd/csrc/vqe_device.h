@@ -1213,7 +1213,10 @@ __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L,
 typedef __attribute__((address_space(3))) double lds_double;
 struct NoSide { __device__ __forceinline__ void operator()() const {} };
 
-template <int N>
+// WIDE: compile the workgroup-wide update in (always for n >= 10; below that only in the kernel variant that is
+// launched for batches with more than 64 parameters - the trainable regime - because its registers cost the
+// 128-VGPR kernels 10-20 % at small parameter counts)
+template <int N, bool WIDE = (N >= 10)>
 struct StagedCobyla {
   static constexpr int kThreads = Geo<N>::NT;
   typedef cby::CobylaM0<WaveCtx, false, lds_double> CobL;   // arrays in LDS (ds_ instructions)
@@ -1234,9 +1237,7 @@ struct StagedCobyla {
     n = n_;
     words = (int)cby::scratch_doubles(n, WaveCtx::kPad);
     red = L.red;
-    // (n <= 9: the 128-VGPR kernels lose 10-20 % to spills when a third variant is compiled in,
-    // and gain only 13 % at ~129 parameters: they keep the single-wave variants)
-    block = N >= 10 && n > 64;
+    block = WIDE && n > 64;
     staged = !block && (size_t)words * 8 <= ((size_t)16 << N);
     if (block) words = (int)cby::scratch_doubles(n, BlockCtx<Geo<N>::NT>::kPad);
   }
@@ -1333,8 +1334,8 @@ struct StagedCobyla {
 #ifdef VQE_STAMPS
     const long long t1 = clock64();
 #endif
-    if (N >= 10 && block) {
-      if constexpr (N >= 10) {
+    if (WIDE && block) {
+      if constexpr (WIDE) {
         if (threadIdx.x >= 64 && threadIdx.x < 128) side();
         call<FIRST, CobB>(gmem, f, rhobeg, rhoend, maxfun);     // all threads: contains barriers
       }
@@ -1426,7 +1427,7 @@ __global__ void __launch_bounds__(Geo<N>::NT) k_lds_state(BatchArgs A) {
 // circuit WITHOUT gate g (the action just taken; its angle, if it is a rotation, is not a
 // variable), and with env_step = 1 the optimum is rounded to float32 (the state tensor's
 // dtype, :480) and the energy of the FULL circuit is reported (:291).
-template <int N>
+template <int N, bool WIDE = (N >= 10)>
 __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchArgs A) {
   constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1454,7 +1455,7 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
   const int Popt = P - (p_hole >= 0);
   stage_groups(A.ham, L);
   if constexpr (N >= 10) stage_cls<N>(A.ham, L);
-  StagedCobyla<N> sc;
+  StagedCobyla<N, WIDE> sc;
   // phases: 0 = single evaluation (empty x0: scipy returns after one call), 1 = COBYLA loop,
   // 2 = post-action evaluation of env_step.  ONE evaluation call site keeps everything inlined.
   int phase = 0, nfev = 1;
