@@ -489,6 +489,36 @@ def noisy_aux(tq, n, ham, psi0, batch, B, G, maxfun):
             "mean_energy": float(np.mean(f)), "noise": "Pauli trajectories, one draw per (environment, evaluation, gate)"}
 
 
+def trainable8_aux(tq, B=4096, G=150, maxfun=300):
+    """BASELINE config 2 regime: 8-qubit H2O (the shipped 193-term Hamiltonian), circuits of the size the trainable
+    path starts from (150 gates, ~129 rotations, all of them variables; reference environment_qulacs.py:285-328),
+    from |0...0>, fused minimisation with maxfun 300: the optimiser's 2 x 137^2 matrices live in L2 here and its
+    update is most of an evaluation."""
+    n = 8
+    ham = tq.hamiltonian.load_npz(os.path.join(ROOT, "tests", "golden", "ham_H2O_8q.npz"), n)
+    rng = np.random.default_rng(0)
+    kind = np.where(rng.random((B, G)) < 0.14, 0, rng.integers(1, 4, (B, G))).astype(np.int32)
+    c = rng.integers(0, n, (B, G))
+    t = (c + 1 + rng.integers(0, n - 1, (B, G))) % n
+    q0 = np.where(kind == 0, c, rng.integers(0, n, (B, G))).astype(np.int32)
+    q1 = np.where(kind == 0, t, -1).astype(np.int32)
+    rot = kind != 0
+    pidx = np.where(rot, np.cumsum(rot, axis=1) - 1, -1).astype(np.int32)
+    par_off = np.concatenate([[0], np.cumsum(rot.sum(1))]).astype(np.int64)
+    theta = rng.uniform(-np.pi, np.pi, int(par_off[-1]))
+    eng = tq.VQEEngine(n)
+    eng.set_hamiltonian(ham.xmask, ham.zmask, ham.coeff)
+    eng.batch_load_flat(np.arange(B + 1, dtype=np.int64) * G, kind.ravel(), q0.ravel(), q1.ravel(), pidx.ravel(), par_off, theta)
+    for _ in range(2):
+        eng.batch_run_minimize(1.0, 1e-4, maxfun)
+        eng.sync()
+    ms = eng.last_kernel_ms()
+    _, f, nfev = eng.batch_fetch(want_x=False)
+    return {"workload": f"h2o8_193terms_trainable_regime_G{G}_P{rot.sum(1).mean():.0f}_B{B}_maxfun{maxfun}",
+            "evals_per_s_per_gpu": float(nfev.sum()) / (ms * 1e-3), "minimisations_per_s_per_gpu": B / (ms * 1e-3),
+            "mean_nfev": float(nfev.mean()), "kernel_ms": ms, "kernel": "k_lds_minimize<8, wide>", "mean_energy": float(np.mean(f))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -503,6 +533,7 @@ def main():
     ap.add_argument("--no-mps2qc", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the G in {8,32,64,110} auxiliary launches")
     ap.add_argument("--no-noisy", action="store_true", help="skip the fixed_noise (config 5) auxiliary launch")
+    ap.add_argument("--no-trainable8", action="store_true", help="skip the 8-qubit trainable-regime (config 2) auxiliary launch")
     ap.add_argument("--no-episode", action="store_true", help="skip the LIH12q fixed config through VecCircuitEnv")
     ap.add_argument("--episode", action="store_true", help="(default at N = 1; kept for older command lines)")
     ap.add_argument("--episode-envs", type=int, default=4096)
@@ -515,7 +546,7 @@ def main():
     ap.add_argument("--selftest-launch", action="store_true", help="CPU rehearsal of the multi-rank launch path (no GPU work)")
     args = ap.parse_args()
     if args.headline_only:
-        args.no_cpu_baseline = args.no_heis20 = args.no_mps2qc = args.no_sweep = args.no_episode = args.no_noisy = True
+        args.no_cpu_baseline = args.no_heis20 = args.no_mps2qc = args.no_sweep = args.no_episode = args.no_noisy = args.no_trainable8 = True
 
     # ---- launch: under torchrun every process is a rank; started plainly with --gpus N > 1 this process
     # spawns the ranks itself, before anything touches the GPU
@@ -611,6 +642,7 @@ def main():
                 "note": "same circuits, x0 = optimum of the previous step (float32), kernel time only"}
     sweep = None if args.no_sweep else g_sweep(tq, eng, n, B, args.maxfun, rank)
     noisy = None if (args.no_noisy or rank != 0) else noisy_aux(tq, n, ham, psi0, batch, B, G, args.maxfun)
+    train8 = None if (args.no_trainable8 or rank != 0) else trainable8_aux(tq)
 
     episode = None
     if not args.no_episode and rank == 0 and world == 1:
@@ -654,6 +686,8 @@ def main():
             out["gate_sweep"] = sweep
         if noisy is not None:
             out["noisy12"] = noisy
+        if train8 is not None:
+            out["trainable8"] = train8
         if episode is not None:
             out["episode"] = episode
         if heis is not None:
