@@ -63,6 +63,7 @@ struct HostCtx {
   static constexpr int nth = 1;
   static constexpr int kPad = 1;   // inner loops run to exactly n
   static constexpr bool kSplit = false;   // no second lane to share a row with
+  static constexpr bool kColumns = false; // (workgroup contexts: element-wise matrix passes run with the lanes along a row)
   CBY_HD double pair_sum(double v) const { return v; }
   CBY_HD void lockstep() const {}   // see the one call site
 
@@ -530,6 +531,36 @@ struct CobylaM0 {
     ctx.sync();
     for (int i = ctx.tid; i < n; i += ctx.nth) SIMI(jdrop, i) /= temp;
     ctx.sync();
+    if constexpr (Ctx::kColumns) {
+      // Workgroup context: the update is element-wise, so it does not matter who does it - wave w takes rows
+      // w, w + NW, ... with its lanes along the row (coalesced, every thread busy, nothing to reduce; a thread
+      // per row walks 2 nv doubles through L2 with a stride of a whole row between neighbouring lanes).
+      if (!have_tdot) {
+        for (int j = rlane; j < n; j += rstep) {
+          double t = 0.0;
+          for (int i0 = ilo; i0 < ihi; i0 += P) {
+            double v[P], u[P];
+            CBY_FULL_UNROLL
+            for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = dx[i0 + q]; }
+            CBY_FULL_UNROLL
+            for (int q = 0; q < P; ++q) t += v[q] * u[q];
+          }
+          tdot[j] = t;
+        }
+        ctx.sync();
+      }
+      const int wv = ctx.tid >> 6, ln = ctx.tid & 63;
+      for (int j = wv; j < n; j += Ctx::nth / 64) {
+        if (j == jdrop) continue;
+        const double t = tdot[j];
+        for (int i = ln; i < nv; i += 64) {
+          const double v = SIMI(j, i), u = SIMI(jdrop, i);
+          SIMI(j, i) = v - t * u;
+        }
+      }
+      ctx.sync();
+      return;
+    }
     for (int j = rlane; j < n; j += rstep) {
       if (j == jdrop) continue;
       double t = 0.0;

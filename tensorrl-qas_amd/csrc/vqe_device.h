@@ -210,6 +210,7 @@ struct WaveCtx {
   static constexpr int nth = 64;
   static constexpr int kPad = 8;   // inner loops in batches of 8, matrices zero-padded (cobyla_m0.h)
   static constexpr bool kSplit = true;   // <= 32 rows: lanes l and l + 32 share a row
+  static constexpr bool kColumns = false;
   // v + (the value of v in lane ^ 32)
   __device__ __forceinline__ double pair_sum(double v) const {
     const int lo = __double2loint(v), hi = __double2hiint(v);
@@ -274,6 +275,7 @@ struct BlockCtx {
   static constexpr int NW = NT / 64;
   static constexpr int kPad = 8;    // (16 - twice the loads in flight per batch - measured +5 % at 12 qubits / 202 variables)
   static constexpr bool kSplit = false;
+  static constexpr bool kColumns = true;   // element-wise matrix passes with the lanes along a row (cobyla_m0.h: update_simi)
   __device__ __forceinline__ double pair_sum(double v) const { return v; }
   __device__ __forceinline__ void lockstep() const {}   // kSplit = false: a row has one owner
   __device__ __forceinline__ void sync() const { __syncthreads(); }

@@ -40,6 +40,7 @@ struct EmuWaveCtx {
   static constexpr int nth = kLanes;
   static constexpr int kPad = 8;
   static constexpr bool kSplit = true;
+  static constexpr bool kColumns = false;
   void sync() const { pthread_barrier_wait(&g_bar); }
   // value of v in lane `partner(tid)`
   template <class F>
