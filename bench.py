@@ -516,7 +516,7 @@ def trainable8_aux(tq, B=4096, G=150, maxfun=300):
     _, f, nfev = eng.batch_fetch(want_x=False)
     return {"workload": f"h2o8_193terms_trainable_regime_G{G}_P{rot.sum(1).mean():.0f}_B{B}_maxfun{maxfun}",
             "evals_per_s_per_gpu": float(nfev.sum()) / (ms * 1e-3), "minimisations_per_s_per_gpu": B / (ms * 1e-3),
-            "mean_nfev": float(nfev.mean()), "kernel_ms": ms, "kernel": "k_lds_minimize<8, wide>", "mean_energy": float(np.mean(f))}
+            "mean_nfev": float(nfev.mean()), "kernel_ms": ms, "kernel": "k_lds_minimize<8>", "mean_energy": float(np.mean(f))}
 
 
 def main():

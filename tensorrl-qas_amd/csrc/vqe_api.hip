@@ -399,9 +399,10 @@ int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
   // register path: the raw ops are staged in the (idle) state region, 2^n records at most
   if (N >= kRegMinQubits && (size_t)A.max_ops > ((size_t)1 << N))
     return fail(h, VQE_EINVAL, "circuit too large for the LDS-resident path (more than 2^n rotations)");
-  // n = 6..9 with more than 64 parameters in a circuit (the trainable regime): the variant whose optimiser update
-  // runs on the whole workgroup (StagedCobyla<N, WIDE>)
-  constexpr bool kHasWide = N >= 6 && N < 10;
+  // 256-thread workgroups below the register path (n = 9 by default) with more than 64 parameters in a circuit (the
+  // trainable regime): the variant whose optimiser update runs on the whole workgroup (StagedCobyla<N, WIDE>).
+  // One-wave workgroups (n <= kOneWaveMaxQubits) have no second wave to spread it over.
+  constexpr bool kHasWide = N > kOneWaveMaxQubits && N >= 6 && N < 10;
   static const bool wide_on = [] { const char* e = std::getenv("VQE_WIDE_UPDATE"); return !(e && e[0] == '0'); }();   // A/B knob
   const bool wide = kHasWide && wide_on && which == 1 && A.max_params > 64;
   const void* fn = which == 0 ? (const void*)k_lds_energy<N>

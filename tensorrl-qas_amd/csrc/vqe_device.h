@@ -56,10 +56,20 @@ constexpr int kThreads = 256;   // default workgroup size (n <= 11 and the strea
 #endif
 constexpr int kWideMinQubits = VQE_WIDE_MIN;   // 512-thread workgroups from this size on
 
+#ifndef VQE_ONE_WAVE_MAX
+#define VQE_ONE_WAVE_MAX 9
+#endif
+// Up to this size an environment is ONE wavefront (64 threads, 4 amplitudes per thread at 8 qubits).  With four waves
+// per environment three of them sit at a barrier while wave 0 runs the optimiser update, and at this size that update
+// is most of an evaluation: one-wave workgroups keep 16 environments per CU busy instead of 4 (8 qubits, 20 gates:
+// 46.9 -> 92.4 M evaluations/s; 150 gates: 12.9 -> 13.2 M; 129 variables: 6.3 -> 5.8 M at 4096 environments, 6.4 M
+// at 16384 - the price of having no second wave for the workgroup-wide update).
+constexpr int kOneWaveMaxQubits = VQE_ONE_WAVE_MAX;
+
 template <int N>
 struct Geo {
-  static constexpr int NT = N >= kWideMinQubits ? 512 : 256;   // threads per workgroup
-  static constexpr int LT = N >= kWideMinQubits ? 9 : 8;       // log2(NT)
+  static constexpr int NT = N >= kWideMinQubits ? 512 : (N <= kOneWaveMaxQubits ? 64 : 256);   // threads per workgroup
+  static constexpr int LT = N >= kWideMinQubits ? 9 : (N <= kOneWaveMaxQubits ? 6 : 8);         // log2(NT)
   static constexpr int NW = NT / 64;               // waves per workgroup
   static constexpr int WPS = N <= 11 ? 4 : 2;      // waves per SIMD asked of the register allocator
 };
@@ -191,6 +201,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <int NW = 4>
 __device__ __forceinline__ double block_sum(double v, double* red /* >= NW doubles LDS */) {
   v = wave_sum(v);
+  if constexpr (NW == 1) return v;     // one-wave workgroups: every lane has it already
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -1221,6 +1232,7 @@ struct NoSide { __device__ __forceinline__ void operator()() const {} };
 template <int N, bool WIDE = (N >= 10)>
 struct StagedCobyla {
   static constexpr int kThreads = Geo<N>::NT;
+  static_assert(!WIDE || kThreads >= 256, "the workgroup-wide update wants several waves (a one-wave instantiation hung on the GPU in round 2)");
   typedef cby::CobylaM0<WaveCtx, false, lds_double> CobL;   // arrays in LDS (ds_ instructions)
   typedef cby::CobylaM0<WaveCtx, false, double> CobG;       // arrays in the global scratch, one wave
   typedef cby::CobylaM0<BlockCtx<Geo<N>::NT>, false, double> CobB;   // the same, whole workgroup (more rows than a wave has lanes)
@@ -1338,12 +1350,13 @@ struct StagedCobyla {
 #endif
     if (WIDE && block) {
       if constexpr (WIDE) {
-        if (threadIdx.x >= 64 && threadIdx.x < 128) side();
+        if (kThreads == 64 || (threadIdx.x >= 64 && threadIdx.x < 128)) side();
         call<FIRST, CobB>(gmem, f, rhobeg, rhoend, maxfun);     // all threads: contains barriers
       }
     } else if (threadIdx.x < 64) {
       if (staged) call<FIRST, CobL>((lds_double*)lmem, f, rhobeg, rhoend, maxfun);
       else call<FIRST, CobG>(gmem, f, rhobeg, rhoend, maxfun);
+      if constexpr (kThreads == 64) side();     // one-wave workgroups: no second wave to give the side job to
     } else if (threadIdx.x < 128) {
 #ifdef VQE_STAMPS
       const long long ts0 = clock64();

@@ -7,7 +7,7 @@ n = 8
 case = load_case("H2O_8q")
 xm, zm = tq.hamiltonian.masks_from_strings(case["paulis"], n)
 rng = np.random.default_rng(0)
-B, G, mf = 1024, 150, 300
+B, G, mf = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), 150, 300
 kind = np.where(rng.random((B, G)) < 0.14, 0, rng.integers(1, 4, (B, G))).astype(np.int32)     # ~129 rotations
 c = rng.integers(0, n, (B, G)); t = (c + 1 + rng.integers(0, n - 1, (B, G))) % n
 q0 = np.where(kind == 0, c, rng.integers(0, n, (B, G))).astype(np.int32); q1 = np.where(kind == 0, t, -1).astype(np.int32)
