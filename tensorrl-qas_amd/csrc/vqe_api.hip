@@ -252,7 +252,7 @@ int build_hamiltonian(vqe_t* h) {
   };
   // register path: canonical index p' = M p (see IndexMap); all masks below are in p'
   const bool reg_path = h->lds_path && n >= kRegMinQubits;
-  const int lt = n >= kWideMinQubits ? 9 : 8;      // Geo<N>::LT of the register path
+  const int lt = geo_lt(n);                        // Geo<N>::LT of the register path
   IndexMap im = identity_map(n);
   if (reg_path) {
     std::vector<uint32_t> xs;

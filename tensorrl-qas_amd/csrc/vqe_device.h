@@ -66,12 +66,18 @@ constexpr int kWideMinQubits = VQE_WIDE_MIN;   // 512-thread workgroups from thi
 // at 16384 - the price of having no second wave for the workgroup-wide update).
 constexpr int kOneWaveMaxQubits = VQE_ONE_WAVE_MAX;
 
+#ifndef VQE_ONE_WAVE_REG
+#define VQE_ONE_WAVE_REG 0      // 1: 10 qubits on the register path with one wave (16 amplitudes per thread) - parity green, 0..9 % slower than four waves x 4 amplitudes
+#endif
+__host__ __device__ constexpr bool geo_one_wave(int n) { return n <= kOneWaveMaxQubits || (VQE_ONE_WAVE_REG && n == 10); }
+__host__ __device__ constexpr int geo_lt(int n) { return n >= kWideMinQubits ? 9 : (geo_one_wave(n) ? 6 : 8); }
+
 template <int N>
 struct Geo {
-  static constexpr int NT = N >= kWideMinQubits ? 512 : (N <= kOneWaveMaxQubits ? 64 : 256);   // threads per workgroup
-  static constexpr int LT = N >= kWideMinQubits ? 9 : (N <= kOneWaveMaxQubits ? 6 : 8);         // log2(NT)
+  static constexpr int NT = 1 << geo_lt(N);        // threads per workgroup
+  static constexpr int LT = geo_lt(N);             // log2(NT)
   static constexpr int NW = NT / 64;               // waves per workgroup
-  static constexpr int WPS = N <= 11 ? 4 : 2;      // waves per SIMD asked of the register allocator
+  static constexpr int WPS = (N <= 11 && !(VQE_ONE_WAVE_REG && N == 10)) ? 4 : 2;      // waves per SIMD asked of the register allocator
 };
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -1229,7 +1235,7 @@ struct NoSide { __device__ __forceinline__ void operator()() const {} };
 // WIDE: compile the workgroup-wide update in (always for n >= 10; below that only in the kernel variant that is
 // launched for batches with more than 64 parameters - the trainable regime - because its registers cost the
 // 128-VGPR kernels 10-20 % at small parameter counts)
-template <int N, bool WIDE = (N >= 10)>
+template <int N, bool WIDE = (N >= 10 && Geo<N>::NT >= 256)>
 struct StagedCobyla {
   static constexpr int kThreads = Geo<N>::NT;
   static_assert(!WIDE || kThreads >= 256, "the workgroup-wide update wants several waves (a one-wave instantiation hung on the GPU in round 2)");
@@ -1442,7 +1448,7 @@ __global__ void __launch_bounds__(Geo<N>::NT) k_lds_state(BatchArgs A) {
 // circuit WITHOUT gate g (the action just taken; its angle, if it is a rotation, is not a
 // variable), and with env_step = 1 the optimum is rounded to float32 (the state tensor's
 // dtype, :480) and the energy of the FULL circuit is reported (:291).
-template <int N, bool WIDE = (N >= 10)>
+template <int N, bool WIDE = (N >= 10 && Geo<N>::NT >= 256)>
 __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchArgs A) {
   constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -2,7 +2,7 @@ import sys, numpy as np
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/oracle')
 import tensorrl_qas_amd as tq, bench
 from helpers import random_hamiltonian, random_state
-n = 9; rng = np.random.default_rng(9)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 9; rng = np.random.default_rng(n)
 ham = random_hamiltonian(n, 200, rng); psi0 = random_state(n, rng)
 for B in (4096, 16384):
   for G in (20, 60):
@@ -13,4 +13,4 @@ for B in (4096, 16384):
     for _ in range(2):
         eng.batch_run_env_step(1.0, 1e-4, 300); eng.sync()
     ms = eng.last_kernel_ms(); x, f, nfev = eng.batch_fetch()
-    print(f"n=9 G={G} B={B}: {ms:.1f} ms, {(nfev.sum()+B)/ms/1e3:.2f} M evals/s, mean f {f.mean():.6f}", flush=True)
+    print(f"n={n} G={G} B={B}: {ms:.1f} ms, {(nfev.sum()+B)/ms/1e3:.2f} M evals/s, mean f {f.mean():.6f}", flush=True)
