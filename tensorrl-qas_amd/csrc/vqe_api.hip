@@ -405,16 +405,21 @@ int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
   constexpr bool kHasWide = N > kOneWaveMaxQubits && N >= 6 && N < 10;
   static const bool wide_on = [] { const char* e = std::getenv("VQE_WIDE_UPDATE"); return !(e && e[0] == '0'); }();   // A/B knob
   const bool wide = kHasWide && wide_on && which == 1 && A.max_params > 64;
+  const bool noisy = A.noise.p1 > 0.0 || A.noise.p2 > 0.0;
+  constexpr bool kW = (N >= 10 && Geo<N>::NT >= 256);
   const void* fn = which == 0 ? (const void*)k_lds_energy<N>
-                   : which == 1 ? (wide ? (const void*)k_lds_minimize<N, kHasWide> : (const void*)k_lds_minimize<N>)
+                   : which == 1 ? (wide ? (noisy ? (const void*)k_lds_minimize<N, kHasWide, true> : (const void*)k_lds_minimize<N, kHasWide, false>)
+                                        : (noisy ? (const void*)k_lds_minimize<N, kW, true> : (const void*)k_lds_minimize<N, kW, false>))
                                 : (const void*)k_lds_state<N>;
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   h->last_wg_per_cu = std::max(1, std::min(8, (int)(h->lds_per_cu / lds)));
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
   const dim3 grid(which == 2 ? 1 : A.batch), block(Geo<N>::NT);
   if (which == 0) hipLaunchKernelGGL(k_lds_energy<N>, grid, block, lds, h->stream, A);
-  else if (which == 1 && wide) hipLaunchKernelGGL((k_lds_minimize<N, kHasWide>), grid, block, lds, h->stream, A);
-  else if (which == 1) hipLaunchKernelGGL(k_lds_minimize<N>, grid, block, lds, h->stream, A);
+  else if (which == 1 && wide && noisy) hipLaunchKernelGGL((k_lds_minimize<N, kHasWide, true>), grid, block, lds, h->stream, A);
+  else if (which == 1 && wide) hipLaunchKernelGGL((k_lds_minimize<N, kHasWide, false>), grid, block, lds, h->stream, A);
+  else if (which == 1 && noisy) hipLaunchKernelGGL((k_lds_minimize<N, kW, true>), grid, block, lds, h->stream, A);
+  else if (which == 1) hipLaunchKernelGGL((k_lds_minimize<N, kW, false>), grid, block, lds, h->stream, A);
   else hipLaunchKernelGGL(k_lds_state<N>, grid, block, lds, h->stream, A);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(h->ev1, h->stream));

@@ -675,7 +675,7 @@ __device__ __forceinline__ void compile_all(const BatchArgs& A, int b, uint64_t 
 // Apply the compiled ops to the LDS-resident state, then restore the logical layout.
 // `theta` holds the P parameters of the circuit, or - when p_hole >= 0 - the P-1 parameters
 // of the circuit without the rotation whose parameter index is p_hole.
-template <int N>
+template <int N, bool SLOTS = true>
 __device__ __forceinline__ void run_ops(const Lds& L, const double* theta, int P, int p_hole = -1) {
   constexpr int kThreads = Geo<N>::NT;   // shadows the default: this kernel family's block size
   constexpr uint32_t DIM = 1u << N;
@@ -692,8 +692,8 @@ __device__ __forceinline__ void run_ops(const Lds& L, const double* theta, int P
   const int nops = L.meta[0];
   for (int o = 0; o < nops; ++o) {
     const Op op = L.ops[o];
-    o += (int)((uint32_t)op.kind >> 24);   // inactive noise slots behind this record (jump counts of patch_noise_wave)
     const int kind = op.kind & 0xff;
+    if constexpr (SLOTS) o += (int)((uint32_t)op.kind >> 24);   // inactive noise slots behind this record (jump counts of patch_noise_wave)
     if (kind == OP_NOP) continue;   // inactive noise slot: nothing to do, no barrier needed
     const int inv = (op.kind >> 8) & 1;
     if (kind == OP_RX || kind == OP_RY) {
@@ -1199,18 +1199,18 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H, Hook
 }
 
 // One evaluation with the ops already compiled: circuit, then <psi|H|psi>.
-template <int N, class Hook = NoHook>
+template <int N, bool SLOTS = false, class Hook = NoHook>
 __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L, const double* theta, int P,
                                                int p_hole = -1, Hook after_pairs = Hook()) {
 #ifdef VQE_STAMPS
   const long long t0 = clock64();
 #endif
   if constexpr (N >= kRegMinQubits) {
-    run_ops_reg<N>(L, A.init, theta, P, p_hole, A.dbg);
+    run_ops_reg<N, SLOTS>(L, A.init, theta, P, p_hole, A.dbg);
   } else {
     load_init<N>(L, A.init);
     __syncthreads();
-    run_ops<N>(L, theta, P, p_hole);
+    run_ops<N, SLOTS>(L, theta, P, p_hole);
   }
 #ifdef VQE_STAMPS
   const long long t1 = clock64();
@@ -1410,7 +1410,7 @@ __global__ void __launch_bounds__(Geo<N>::NT) k_lds_energy(BatchArgs A) {
   if constexpr (N >= 10) stage_cls<N>(A.ham, L);
   compile_all<N>(A, b, 0, L, -1, true, noisy);
   if (noisy) patch_noise<N>(A, b, A.noise.eval_base, L, -1, true);
-  double e = lds_evaluate<N>(A, L, A.theta + A.par_begin[b], A.par_count[b]);
+  double e = lds_evaluate<N, true>(A, L, A.theta + A.par_begin[b], A.par_count[b]);
   if (A.noise.shot_sigma != 0.0) e += A.noise.shot_sigma * noise_gauss(A.noise.seed, (uint64_t)b, A.noise.eval_base);
   if (threadIdx.x == 0) { A.fout[b] = e; if (A.nfev) A.nfev[b] = 1; }
 }
@@ -1424,7 +1424,7 @@ __global__ void __launch_bounds__(Geo<N>::NT) k_lds_state(BatchArgs A) {
   compile_all<N>(A, 0, 0, L, -1, false, noisy_state);   // logical order for the read-out
   if (noisy_state) patch_noise<N>(A, 0, A.noise.eval_base, L, -1, false);
   if constexpr (N >= kRegMinQubits) {
-    run_ops_reg<N>(L, A.init, A.theta + A.par_begin[0], A.par_count[0]);
+    run_ops_reg<N, true>(L, A.init, A.theta + A.par_begin[0], A.par_count[0]);
   } else {
     load_init<N>(L, A.init);
     __syncthreads();
@@ -1448,7 +1448,8 @@ __global__ void __launch_bounds__(Geo<N>::NT) k_lds_state(BatchArgs A) {
 // circuit WITHOUT gate g (the action just taken; its angle, if it is a rotation, is not a
 // variable), and with env_step = 1 the optimum is rounded to float32 (the state tensor's
 // dtype, :480) and the energy of the FULL circuit is reported (:291).
-template <int N, bool WIDE = (N >= 10 && Geo<N>::NT >= 256)>
+// NOISY: the stochastic instantiation (depolarising channels): the noiseless one carries none of its code
+template <int N, bool WIDE = (N >= 10 && Geo<N>::NT >= 256), bool NOISY = false>
 __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchArgs A) {
   constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1457,7 +1458,7 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
   const int P = A.par_count[b];
   const double* theta = A.theta + A.par_begin[b];
   double* xout = A.xout + A.par_begin[b];
-  const bool noisy = (A.noise.p1 > 0.0 || A.noise.p2 > 0.0);
+  constexpr bool noisy = NOISY;
   const int skip = A.new_gate ? A.new_gate[b] : -1;
   int p_hole = -1;
   int skip_end = skip + 1;   // (no new gate: the empty range [-1, 0))
@@ -1501,7 +1502,7 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
     if (need_compile) { compile_all<N>(A, b, 0, L, sk, true, noisy, ske); need_compile = false; patched = false; }
     if (noisy && !patched) patch_noise<N>(A, b, eid, L, sk, true, ske);
     patched = false;
-    double e = lds_evaluate<N>(A, L, th, P, ph);
+    double e = lds_evaluate<N, NOISY>(A, L, th, P, ph);
     // finite-shot estimate of <H>: Gaussian with the total standard deviation the caller set
     if (A.noise.shot_sigma != 0.0) e += A.noise.shot_sigma * noise_gauss(A.noise.seed, (uint64_t)b, eid);
     bool finished_opt = false;

@@ -222,7 +222,7 @@ __device__ __forceinline__ void ry_pairs(double2 (&amp)[NA], double c, double s,
 
 // Apply the scheduled ops with the amplitudes in registers; leaves the state in L.psi in
 // LOGICAL order (same contract as run_ops).
-template <int N>
+template <int N, bool SLOTS = false>
 __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restrict__ init, const double* theta, int P,
                                    int p_hole = -1, unsigned long long* __restrict__ dbg = nullptr) {
 #ifdef VQE_STAMPS
@@ -279,7 +279,10 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
   for (int o = 0; o < nops; ++o) {
     const Op op = nxt;
     const double2 cs = ncs;
-    o += (int)((uint32_t)op.kind >> 24);          // inactive noise slots behind this record (an iteration costs ~250 cycles even when it does nothing)
+    // stochastic runs (SLOTS): jump over the inactive noise slots behind this record - an iteration costs ~250 cycles
+    // even when it does nothing.  Compiled into the noisy instantiation only: the address of the next record then waits
+    // for this one, which costs the noiseless kernel 1 % (2 % behind a run-time branch).
+    if constexpr (SLOTS) o += (int)((uint32_t)__builtin_amdgcn_readfirstlane(op.kind) >> 24);
     nxt = L.sched[o + 1];
     ncs = *(const double2*)(cs_b + nxt.pidx);
     const int kind = op.kind & 0xff;
