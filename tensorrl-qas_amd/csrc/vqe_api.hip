@@ -402,11 +402,11 @@ int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
   // 256-thread workgroups below the register path (n = 9 by default) with more than 64 parameters in a circuit (the
   // trainable regime): the variant whose optimiser update runs on the whole workgroup (StagedCobyla<N, WIDE>).
   // One-wave workgroups (n <= kOneWaveMaxQubits) have no second wave to spread it over.
-  constexpr bool kHasWide = N > kOneWaveMaxQubits && N >= 6 && N < 10;
+  constexpr bool kHasWide = Geo<N>::NT >= 256 && N >= 6;
   static const bool wide_on = [] { const char* e = std::getenv("VQE_WIDE_UPDATE"); return !(e && e[0] == '0'); }();   // A/B knob
   const bool wide = kHasWide && wide_on && which == 1 && A.max_params > 64;
   const bool noisy = A.noise.p1 > 0.0 || A.noise.p2 > 0.0;
-  constexpr bool kW = (N >= 10 && Geo<N>::NT >= 256);
+  constexpr bool kW = false;     // up to 64 parameters per circuit: the instantiation without the workgroup-wide update
   const void* fn = which == 0 ? (const void*)k_lds_energy<N>
                    : which == 1 ? (wide ? (noisy ? (const void*)k_lds_minimize<N, kHasWide, true> : (const void*)k_lds_minimize<N, kHasWide, false>)
                                         : (noisy ? (const void*)k_lds_minimize<N, kW, true> : (const void*)k_lds_minimize<N, kW, false>))
