@@ -24,6 +24,7 @@
 // vertex; on maxfun termination it is the best vertex.
 #pragma once
 #include <math.h>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #define CBY_HD __host__ __device__ __forceinline__
@@ -130,6 +131,12 @@ struct CobylaM0 {
   // scalars, identical in every thread
   double rho, prerem, parsig, pareta, fbest_ret;
   int nfvals, jdrop, ibrnch, iflag, ifull, status;
+  // veta[] (vertex lengths) depends on sim alone and a step replaces ONE vertex: vcol = -2: all of it is stale, -1: all
+  // valid, j >= 0: only entry j is stale (same values as a full recomputation, one sweep over sim saved per iteration)
+  int vcol;
+  // (only where the arrays live in global memory - plain `double` - : with LDS-resident arrays the sweep is cheap and
+  // the extra branch costs the fused 12-qubit kernel 0.8 %)
+  static constexpr bool kIncrementalEta = std::is_same<Real, double>::value;
 
   CBY_HD Real &SIM(int i, int j) { return sim[(size_t)j * ld + i]; }    // coordinate i of vertex j
   CBY_HD Real &SIMI(int j, int i) { return simi[(size_t)j * ld + i]; }  // row j of the inverse
@@ -166,20 +173,20 @@ struct CobylaM0 {
     if (ctx.tid == 0) {
       st[0] = rho; st[1] = prerem; st[2] = parsig; st[3] = pareta; st[4] = fbest_ret; st[5] = rhoend;
       st[6] = (double)nfvals; st[7] = (double)jdrop; st[8] = (double)ibrnch; st[9] = (double)iflag;
-      st[10] = (double)ifull; st[11] = (double)status; st[12] = (double)maxfun;
+      st[10] = (double)ifull; st[11] = (double)status; st[12] = (double)maxfun; st[13] = (double)vcol;
     }
     ctx.sync();
   }
   CBY_HD void load_state() {
     rho = st[0]; prerem = st[1]; parsig = st[2]; pareta = st[3]; fbest_ret = st[4]; rhoend = st[5];
     nfvals = (int)st[6]; jdrop = (int)st[7]; ibrnch = (int)st[8]; iflag = (int)st[9];
-    ifull = (int)st[10]; status = (int)st[11]; maxfun = (int)st[12];
+    ifull = (int)st[10]; status = (int)st[11]; maxfun = (int)st[12]; vcol = (int)st[13];
   }
 
   // Begin a minimisation; x[] must already hold x0.  Returns 1 when f(x) is wanted.
   CBY_HD int start(double rhobeg, double rhoend_, int maxfun_) {
     rho = rhobeg; rhoend = rhoend_; maxfun = maxfun_;
-    nfvals = 0; ibrnch = 0; iflag = 0; ifull = 1; status = RUNNING; prerem = 0.0;
+    nfvals = 0; ibrnch = 0; iflag = 0; ifull = 1; status = RUNNING; prerem = 0.0; vcol = -2;
     const double temp = 1.0 / rho;
     if (Ctx::kPad > 1) {   // padding entries must read as zero from now on
       const int total = (int)(st - sim);
@@ -196,6 +203,8 @@ struct CobylaM0 {
     ctx.sync();
     return request_eval();
   }
+
+  CBY_HD void vertex_changed(int j) { vcol = (vcol == -1 || vcol == j) ? j : -2; }
 
   // Label 40: decide whether another evaluation may be made.
   CBY_HD int request_eval() {
@@ -336,6 +345,7 @@ struct CobylaM0 {
         CBY_LOG("140: nfvals %d nbest %d phimin %.17g rho %g ibrnch %d", nfvals, nbest, phimin, rho, ibrnch);
         ctx.sync();
         if (nbest < n) {
+          vcol = -2;   // every vertex moves relative to the new pole
           if (ctx.tid == 0) { const double t = datmat[nv]; datmat[nv] = datmat[nbest]; datmat[nbest] = t; }
           for (int i = rlane; i < n; i += rstep) {
             const double temp = SIM(i, nbest);
@@ -392,18 +402,31 @@ struct CobylaM0 {
         int flag_bad = 0;
         for (int j = rlane; j < n; j += rstep) {
           double wsig = 0.0, weta = 0.0;
-          for (int i0 = ilo; i0 < ihi; i0 += P) {
-            double v[P], u[P];
-            CBY_FULL_UNROLL
-            for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = SIM(i0 + q, j); }
-            CBY_FULL_UNROLL
-            for (int q = 0; q < P; ++q) { wsig += v[q] * v[q]; weta += u[q] * u[q]; }
+          const bool need_eta = !kIncrementalEta || vcol == -2 || j == vcol;
+          if (need_eta) {
+            for (int i0 = ilo; i0 < ihi; i0 += P) {
+              double v[P], u[P];
+              CBY_FULL_UNROLL
+              for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = SIM(i0 + q, j); }
+              CBY_FULL_UNROLL
+              for (int q = 0; q < P; ++q) { wsig += v[q] * v[q]; weta += u[q] * u[q]; }
+            }
+          } else {
+            for (int i0 = ilo; i0 < ihi; i0 += P) {
+              double v[P];
+              CBY_FULL_UNROLL
+              for (int q = 0; q < P; ++q) v[q] = SIMI(j, i0 + q);
+              CBY_FULL_UNROLL
+              for (int q = 0; q < P; ++q) wsig += v[q] * v[q];
+            }
           }
           if (split) { wsig = ctx.pair_sum(wsig); weta = ctx.pair_sum(weta); }
-          const double vs = 1.0 / sqrt(wsig), ve = sqrt(weta);
-          vsig[j] = vs; veta[j] = ve;
+          const double vs = 1.0 / sqrt(wsig), ve = need_eta ? sqrt(weta) : (double)veta[j];
+          vsig[j] = vs;
+          if (need_eta) veta[j] = ve;
           if (vs < parsig || ve > pareta) flag_bad = 1;
         }
+        vcol = -1;
         iflag = ctx.all_or(flag_bad) ? 0 : 1;  // all_or synchronises
         CBY_LOG("    acceptable %d (parsig %.17g pareta %.17g)", iflag, parsig, pareta);
         CBY_STAMP(5);
@@ -425,6 +448,7 @@ struct CobylaM0 {
           dx[i] = d;
           SIM(i, jdrop) = d;
         }
+        vertex_changed(jdrop);
         ctx.sync();
         update_simi(false);
         for (int j = ctx.tid; j < n; j += ctx.nth) x[j] = SIM(j, nv) + dx[j];
@@ -500,6 +524,7 @@ struct CobylaM0 {
         jdrop = jd;
         ctx.sync();
         for (int i = ctx.tid; i < n; i += ctx.nth) SIM(i, jdrop) = dx[i];
+        vertex_changed(jdrop);
         if (ctx.tid == 0) datmat[jdrop] = f;
         ctx.sync();
         CBY_STAMP(1);
