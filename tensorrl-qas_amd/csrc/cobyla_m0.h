@@ -134,6 +134,7 @@ struct CobylaM0 {
   // veta[] (vertex lengths) depends on sim alone and a step replaces ONE vertex: vcol = -2: all of it is stale, -1: all
   // valid, j >= 0: only entry j is stale (same values as a full recomputation, one sweep over sim saved per iteration)
   int vcol;
+  int vrow;   // the same for vsig[] (row norms of simi): update_simi leaves them all valid, a pole move spoils one row
   // (only where the arrays live in global memory - plain `double` - : with LDS-resident arrays the sweep is cheap and
   // the extra branch costs the fused 12-qubit kernel 0.8 %)
   static constexpr bool kIncrementalEta = std::is_same<Real, double>::value;
@@ -173,20 +174,20 @@ struct CobylaM0 {
     if (ctx.tid == 0) {
       st[0] = rho; st[1] = prerem; st[2] = parsig; st[3] = pareta; st[4] = fbest_ret; st[5] = rhoend;
       st[6] = (double)nfvals; st[7] = (double)jdrop; st[8] = (double)ibrnch; st[9] = (double)iflag;
-      st[10] = (double)ifull; st[11] = (double)status; st[12] = (double)maxfun; st[13] = (double)vcol;
+      st[10] = (double)ifull; st[11] = (double)status; st[12] = (double)maxfun; st[13] = (double)(vcol + 2 + 1024 * (vrow + 2));
     }
     ctx.sync();
   }
   CBY_HD void load_state() {
     rho = st[0]; prerem = st[1]; parsig = st[2]; pareta = st[3]; fbest_ret = st[4]; rhoend = st[5];
     nfvals = (int)st[6]; jdrop = (int)st[7]; ibrnch = (int)st[8]; iflag = (int)st[9];
-    ifull = (int)st[10]; status = (int)st[11]; maxfun = (int)st[12]; vcol = (int)st[13];
+    ifull = (int)st[10]; status = (int)st[11]; maxfun = (int)st[12]; { const int pk = (int)st[13]; vcol = pk % 1024 - 2; vrow = pk / 1024 - 2; }
   }
 
   // Begin a minimisation; x[] must already hold x0.  Returns 1 when f(x) is wanted.
   CBY_HD int start(double rhobeg, double rhoend_, int maxfun_) {
     rho = rhobeg; rhoend = rhoend_; maxfun = maxfun_;
-    nfvals = 0; ibrnch = 0; iflag = 0; ifull = 1; status = RUNNING; prerem = 0.0; vcol = -2;
+    nfvals = 0; ibrnch = 0; iflag = 0; ifull = 1; status = RUNNING; prerem = 0.0; vcol = -2; vrow = -2;
     const double temp = 1.0 / rho;
     if (Ctx::kPad > 1) {   // padding entries must read as zero from now on
       const int total = (int)(st - sim);
@@ -346,6 +347,7 @@ struct CobylaM0 {
         ctx.sync();
         if (nbest < n) {
           vcol = -2;   // every vertex moves relative to the new pole
+          vrow = (vrow == -1 || vrow == nbest) ? nbest : -2;   // row nbest of simi is replaced below
           if (ctx.tid == 0) { const double t = datmat[nv]; datmat[nv] = datmat[nbest]; datmat[nbest] = t; }
           for (int i = rlane; i < n; i += rstep) {
             const double temp = SIM(i, nbest);
@@ -403,6 +405,11 @@ struct CobylaM0 {
         for (int j = rlane; j < n; j += rstep) {
           double wsig = 0.0, weta = 0.0;
           const bool need_eta = !kIncrementalEta || vcol == -2 || j == vcol;
+          const bool need_sig = !kIncrementalEta || vrow == -2 || j == vrow;
+          if (!need_sig && !need_eta) {
+            if (vsig[j] < parsig || veta[j] > pareta) flag_bad = 1;
+            continue;
+          }
           if (need_eta) {
             for (int i0 = ilo; i0 < ihi; i0 += P) {
               double v[P], u[P];
@@ -426,7 +433,7 @@ struct CobylaM0 {
           if (need_eta) veta[j] = ve;
           if (vs < parsig || ve > pareta) flag_bad = 1;
         }
-        vcol = -1;
+        vcol = -1; vrow = -1;
         iflag = ctx.all_or(flag_bad) ? 0 : 1;  // all_or synchronises
         CBY_LOG("    acceptable %d (parsig %.17g pareta %.17g)", iflag, parsig, pareta);
         CBY_STAMP(5);
@@ -583,6 +590,7 @@ struct CobylaM0 {
           SIMI(j, i) = v - t * u;
         }
       }
+      vrow = -2;   // (the row norms are not formed on this path)
       ctx.sync();
       return;
     }
@@ -601,13 +609,38 @@ struct CobylaM0 {
         }
         if (split) t = ctx.pair_sum(t);
       }
+      double ws = 0.0;
       for (int i0 = ilo; i0 < ihi; i0 += P) {
         double v[P], u[P];
         CBY_FULL_UNROLL
         for (int q = 0; q < P; ++q) { v[q] = SIMI(j, i0 + q); u[q] = SIMI(jdrop, i0 + q); }
         CBY_FULL_UNROLL
-        for (int q = 0; q < P; ++q) SIMI(j, i0 + q) = v[q] - t * u[q];
+        for (int q = 0; q < P; ++q) {
+          const double nw = v[q] - t * u[q];
+          SIMI(j, i0 + q) = nw;
+          if (kIncrementalEta) ws += nw * nw;     // the row norm the next acceptability test wants: same order as there
+        }
       }
+      if (kIncrementalEta) {
+        if (split) ws = ctx.pair_sum(ws);
+        vsig[j] = 1.0 / sqrt(ws);
+      }
+    }
+    if (kIncrementalEta) {   // ... and the norm of the rescaled row jdrop, by its owner
+      for (int j = rlane; j < n; j += rstep) {
+        if (j != jdrop) continue;
+        double ws = 0.0;
+        for (int i0 = ilo; i0 < ihi; i0 += P) {
+          double v[P];
+          CBY_FULL_UNROLL
+          for (int q = 0; q < P; ++q) v[q] = SIMI(j, i0 + q);
+          CBY_FULL_UNROLL
+          for (int q = 0; q < P; ++q) ws += v[q] * v[q];
+        }
+        if (split) ws = ctx.pair_sum(ws);
+        vsig[j] = 1.0 / sqrt(ws);
+      }
+      vrow = -1;
     }
     ctx.sync();
   }
