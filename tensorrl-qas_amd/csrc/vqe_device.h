@@ -376,18 +376,36 @@ struct Lds {
   int32_t* meta;    // [8]: n_ops, offset c (as the final scatter wants it), phase power, permuted flag, n_sched, n_layouts, permuted by CNOTs alone, raw offset c
   uint32_t* sb;     // [16] scheduler scratch
   uint16_t* sidx;   // [max_ops] position of raw op k in the executed list (sched for n >= 10, ops below)
+  double* cob;      // the optimiser's arrays (cobyla_resident_bytes), or nullptr
 };
 
 // n >= 10: the raw ops only live while the schedule is built, in the (idle) state region: in its
 // upper half next to the staged gate records when they fit there, else in all of it (launch_lds
 // refuses circuits with more than 2^n ops).
 __host__ __device__ inline bool ops_fit_upper_half(int n, int max_ops) { return (size_t)max_ops <= ((size_t)1 << n) / 2; }
-__host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params, int n_groups) {
+__host__ __device__ inline size_t lds_bytes_base(int n, int max_ops, int max_params, int n_groups) {
   const int ng = n_groups > 0 ? n_groups : 1;
   size_t b = (size_t)16 << n;
   b += n >= 10 ? (size_t)16 * (2 * max_ops + 2) + (size_t)32 * (max_ops + 2) : (size_t)16 * max_ops;
   b += (size_t)16 * max_params + (size_t)16 * ng + (n >= 10 ? (size_t)48 * ng : 0);
   return b + 128 + 128 + 128 + 32 + 64 + (((size_t)2 * max_ops + 15) & ~(size_t)15);
+}
+// One-wave workgroups (n <= kOneWaveMaxQubits): the optimiser's arrays get an LDS region of their own when the
+// workgroup then still fits eight times into a CU - no staging copies, no global-memory round trips in the update,
+// which is all of the critical path when an environment is one wave.  0: none (the arrays are staged into the idle
+// state region when they fit there, else they stay in the global scratch).
+#ifndef VQE_RESIDENT_BUDGET
+#define VQE_RESIDENT_BUDGET (160 * 1024 / 8)
+#endif
+constexpr size_t kResidentLdsBudget = VQE_RESIDENT_BUDGET;
+__host__ __device__ inline size_t cobyla_resident_bytes(int n, int max_ops, int max_params, int n_groups) {
+  if (n > kOneWaveMaxQubits || max_params <= 0) return 0;
+  const size_t need = (cby::scratch_doubles(max_params, 8) * 8 + 15) & ~(size_t)15;
+  return lds_bytes_base(n, max_ops, max_params, n_groups) + need + 16 <= kResidentLdsBudget ? need : 0;
+}
+__host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params, int n_groups) {
+  const size_t r = cobyla_resident_bytes(n, max_ops, max_params, n_groups);
+  return ((lds_bytes_base(n, max_ops, max_params, n_groups) + 15) & ~(size_t)15) + r;
 }
 
 __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, int max_params, int n_groups) {
@@ -413,6 +431,9 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, in
   l.meta = (int32_t*)base; base += 32;
   l.sb = (uint32_t*)base; base += 64;
   l.sidx = (uint16_t*)base;
+  l.cob = cobyla_resident_bytes(n, max_ops, max_params, n_groups)
+              ? (double*)((unsigned char*)l.psi + ((lds_bytes_base(n, max_ops, max_params, n_groups) + 15) & ~(size_t)15))
+              : nullptr;
   return l;
 }
 
@@ -1249,27 +1270,29 @@ struct StagedCobyla {
   int* pub;        // LDS: what wave 0 publishes to the workgroup after a call
   int n, words;
   bool staged;
+  bool resident;   // the arrays live in an LDS region of their own (Lds::cob): nothing is copied
   int want, nfvals;   // published after start()/tell()
   __device__ __forceinline__ void init(double* global_scratch, const Lds& L, int n_) {
     gmem = global_scratch;
-    lmem = (double*)L.psi;
+    resident = L.cob != nullptr;
+    lmem = resident ? L.cob : (double*)L.psi;
     pub = (int*)(L.red + 8);
     n = n_;
     words = (int)cby::scratch_doubles(n, WaveCtx::kPad);
     red = L.red;
     block = WIDE && n > 64;
-    staged = !block && (size_t)words * 8 <= ((size_t)16 << N);
+    staged = resident || (!block && (size_t)words * 8 <= ((size_t)16 << N));
     if (block) words = (int)cby::scratch_doubles(n, BlockCtx<Geo<N>::NT>::kPad);
   }
-  __device__ __forceinline__ double* x() const { return gmem; }
+  __device__ __forceinline__ double* x() const { return resident ? lmem : gmem; }
   // the optimiser's scalars as parked in the scratch (valid after start()/tell())
-  __device__ __forceinline__ const double* state() const { return gmem + words - cby::kStateDoubles; }
+  __device__ __forceinline__ const double* state() const { return (resident ? lmem : gmem) + words - cby::kStateDoubles; }
   // Staging copies: all loads of a thread are issued before its first store (a plain strided loop
   // waits for every load in turn: ~5 dependent L2 round trips per call), in chunks of kStage
   // double2 per thread.
   static constexpr int kStage = 6;
   __device__ __forceinline__ void in() {
-    if (!staged) return;
+    if (!staged || resident) return;
     const double2* s = (const double2*)gmem;
     double2* d = (double2*)lmem;
     const int nw = (words + 1) / 2;
@@ -1296,7 +1319,7 @@ struct StagedCobyla {
     if (threadIdx.x == 0) { pub[0] = want; pub[1] = nfvals; }
     __syncthreads();
     want = pub[0]; nfvals = pub[1];
-    if (!staged) return;
+    if (!staged || resident) return;
     const double2* s = (const double2*)lmem;
     double2* d = (double2*)gmem;
     const int nw = (words + 1) / 2;
