@@ -14,3 +14,9 @@ for B in (4096, 16384):
         eng.batch_run_env_step(1.0, 1e-4, 300); eng.sync()
     ms = eng.last_kernel_ms(); x, f, nfev = eng.batch_fetch()
     print(f"n={n} G={G} B={B}: {ms:.1f} ms, {(nfev.sum()+B)/ms/1e3:.2f} M evals/s, mean f {f.mean():.6f}", flush=True)
+    try:
+        c = eng.debug_counters().astype(float)
+        if c[0] > 0:
+            print(f"   stamps per evaluation: circuit {c[1]/c[0]:.0f}  energy {c[2]/c[0]:.0f}  optimiser {c[3]/c[0]:.0f} cycles", flush=True)
+    except Exception:
+        pass
