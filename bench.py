@@ -460,6 +460,72 @@ def g_sweep(tq, eng, n, B, maxfun, rank):
     return out
 
 
+def episode8_aux(tq, torch, dev, num_envs=8192):
+    """The configuration the reference ships most often: TensorRL_fixed/H2O8q_TNbond2 - the shipped 193-term Hamiltonian
+    and chi = 2 init circuit (fixtures under tests/golden/: data of the reference, with the parsed config), 20 steps per
+    episode - through VecCircuitEnv with the compiled host loop, uniformly random legal actions, two half batches
+    software pipelined, one process.  (configuration_files/TensorRL_fixed/H2O8q_TNbond2.cfg of the reference)"""
+    import tempfile
+    from tensorrl_qas_amd.environments.environment_qulacs_TN_notin_agent import CircuitEnv
+    from tensorrl_qas_amd.environments.vec_env import VecCircuitEnv
+    gold = os.path.join(ROOT, "tests", "golden")
+    conf = json.load(open(os.path.join(gold, "host_logic.json")))["configs"]["TensorRL_fixed/H2O8q_TNbond2"]
+    conf = json.loads(json.dumps(conf))
+    root = tempfile.mkdtemp(prefix="h2o8_")
+    os.makedirs(os.path.join(root, "mol_data"))
+    os.makedirs(os.path.join(root, "init_state_circ"))
+    stem = "H2O_8q_geom_H_-0.021_-0.002_0.000;_O_0.835_0.452_0.000;_H_1.477_-0.273_0.000_jordan_wigner"
+    d = np.load(os.path.join(gold, "ham_H2O_8q.npz"))
+    np.savez(os.path.join(root, "mol_data", stem + ".npz"), paulis=np.array([str(x) for x in d["paulis"]]),
+             weights=np.asarray(d["weights"], float), eigvals=np.asarray(d["eigvals"], float), energy_shift=0)
+    names = {0: "cx", 1: "rx", 2: "ry", 3: "rz"}
+    lines = ["OPENQASM 2.0;", 'include "qelib1.inc";', f"qreg q[{int(d['n'])}];"]
+    for nm, a, bq, ang in zip(d["gate_name"], d["gate_q0"], d["gate_q1"], d["gate_angle"]):
+        lines.append(f"cx q[{int(a)}],q[{int(bq)}];" if int(nm) == 0 else f"{names[int(nm)]}({float(ang)!r}) q[{int(a)}];")
+    with open(os.path.join(root, "init_state_circ", f"init_{stem}_TNbond2.qasm"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    conf["env"]["data_root"] = root
+    half = max(1, num_envs // 2)
+    vecs = [VecCircuitEnv(CircuitEnv, conf, torch.device(f"cuda:{dev}"), half, seed=s, native=True) for s in (0, 1)]
+    tdict = vecs[0]._proto._actions_table
+    table = np.array([tdict[i] for i in range(len(tdict))], np.int32)
+    rng = np.random.default_rng(7)
+    for v in vecs:
+        v.reset()
+    n_steps = vecs[0]._proto.num_layers_termination
+
+    def choose(vec):
+        ill = vec.illegal_actions_array()
+        a = rng.integers(0, table.shape[0], vec.num_envs)
+        bad = (ill == a[:, None]).any(axis=1)
+        while bad.any():
+            a[bad] = rng.integers(0, table.shape[0], int(bad.sum()))
+            bad = (ill == a[:, None]).any(axis=1)
+        return table[a]
+
+    steps = 0
+    nfev = t_gpu = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vecs[0].step_async(choose(vecs[0]))
+    for it in range(n_steps):
+        vecs[1].step_async(choose(vecs[1]))
+        for k in (0, 1):
+            vecs[k].step_wait()
+            t_gpu += vecs[k].engine.last_kernel_ms() * 1e-3
+            steps += half
+            nfev += float(np.sum(vecs[k].nfev))
+            if k == 0 and it + 1 < n_steps:
+                vecs[0].step_async(choose(vecs[0]))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    err = np.concatenate([v.errors for v in vecs])
+    return {"config": "TensorRL_fixed/H2O8q_TNbond2 (shipped Hamiltonian and init circuit)", "envs": 2 * half,
+            "steps_per_episode": int(n_steps), "env_steps": steps, "env_steps_per_s_wall": steps / dt,
+            "env_steps_per_s_device": steps / t_gpu, "mean_nfev": nfev / steps, "final_error_min_Ha": float(err.min()),
+            "host_loop": "native (csrc/vec_env.cpp), one process, two half batches pipelined"}
+
+
 def noisy_aux(tq, n, ham, psi0, batch, B, G, maxfun):
     """BASELINE config 5 at bench size: the same circuits with a depolarising channel behind every gate
     (p1 = 0.01, p2 = 0.05; reference environments/VQAs/VQE_qulacs_TN_notin_RL_noise.py:13-54), one Pauli
@@ -534,6 +600,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the G in {8,32,64,110} auxiliary launches")
     ap.add_argument("--no-noisy", action="store_true", help="skip the fixed_noise (config 5) auxiliary launch")
     ap.add_argument("--no-trainable8", action="store_true", help="skip the 8-qubit trainable-regime (config 2) auxiliary launch")
+    ap.add_argument("--no-episode8", action="store_true", help="skip the shipped H2O-8q configuration through VecCircuitEnv")
     ap.add_argument("--no-episode", action="store_true", help="skip the LIH12q fixed config through VecCircuitEnv")
     ap.add_argument("--episode", action="store_true", help="(default at N = 1; kept for older command lines)")
     ap.add_argument("--episode-envs", type=int, default=4096)
@@ -546,7 +613,7 @@ def main():
     ap.add_argument("--selftest-launch", action="store_true", help="CPU rehearsal of the multi-rank launch path (no GPU work)")
     args = ap.parse_args()
     if args.headline_only:
-        args.no_cpu_baseline = args.no_heis20 = args.no_mps2qc = args.no_sweep = args.no_episode = args.no_noisy = args.no_trainable8 = True
+        args.no_cpu_baseline = args.no_heis20 = args.no_mps2qc = args.no_sweep = args.no_episode = args.no_noisy = args.no_trainable8 = args.no_episode8 = True
 
     # ---- launch: under torchrun every process is a rank; started plainly with --gpus N > 1 this process
     # spawns the ranks itself, before anything touches the GPU
@@ -647,6 +714,9 @@ def main():
     episode = None
     if not args.no_episode and rank == 0 and world == 1:
         episode = episode_aux(tq, torch, local, args.episode_envs, args.episode_steps)
+    episode8 = None
+    if not args.no_episode8 and rank == 0 and world == 1:
+        episode8 = episode8_aux(tq, torch, local)
     if world > 1:
         dist.barrier()
 
@@ -690,6 +760,8 @@ def main():
             out["trainable8"] = train8
         if episode is not None:
             out["episode"] = episode
+        if episode8 is not None:
+            out["episode8"] = episode8
         if heis is not None:
             out["heis20"] = heis
         if not args.no_mps2qc:
