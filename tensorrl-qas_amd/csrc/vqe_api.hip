@@ -245,7 +245,7 @@ int build_hamiltonian(vqe_t* h) {
   std::vector<int32_t> tab_r, tab_i;
   std::vector<double> tables;
   // LDS-path order: diagonal group first, then real-table groups (padded with zero-table
-  // dummy groups to a multiple of kEnergyPD), then groups that also need an imaginary table.
+  // dummy groups to a multiple of energy_pd(n)), then groups that also need an imaginary table.
   auto group_has_im = [&](int g) {
     for (int k : h->group_terms[g]) if (h->hci[k] != 0.0) return true;
     return false;
@@ -275,7 +275,7 @@ int build_hamiltonian(vqe_t* h) {
       return rank_of(a) != rank_of(b) ? rank_of(a) < rank_of(b) : top_bit(a) > top_bit(b);
     });
   int has_diag = 0, n_real = 0, n_cls = 0;
-  auto add_dummy = [&](uint32_t xd) {   // zero table: pads a section to a multiple of kEnergyPD
+  auto add_dummy = [&](uint32_t xd) {   // zero table: pads a section to a multiple of energy_pd(n)
     gx.push_back(xd);
     term_off.push_back((int32_t)term_z.size());
     tab_r.push_back((int32_t)tables.size());
@@ -285,8 +285,8 @@ int build_hamiltonian(vqe_t* h) {
   int cur_rank = 0;
   auto enter_section = [&](int rank) {   // rank 4 = end of the list
     if (h->lds_path) {
-      if (cur_rank <= 1 && rank >= 2) while (n_cls % kEnergyPD) { add_dummy(1u << lt); ++n_cls; ++n_real; }
-      if (cur_rank <= 2 && rank >= 3) while ((n_real - n_cls) % kEnergyPD) { add_dummy(1u); ++n_real; }
+      if (cur_rank <= 1 && rank >= 2) while (n_cls % energy_pd(n)) { add_dummy(1u << lt); ++n_cls; ++n_real; }
+      if (cur_rank <= 2 && rank >= 3) while ((n_real - n_cls) % energy_pd(n)) { add_dummy(1u); ++n_real; }
     }
     cur_rank = rank;
   };

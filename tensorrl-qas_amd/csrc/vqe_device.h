@@ -100,11 +100,11 @@ struct HamDev {
   const int32_t* tab_i;     // [n_groups] offset of the imaginary table or -1
   const double* tables;
   int has_diag;             // 1: group 0 is the diagonal (x == 0) group
-  int n_real;               // real-table pair groups incl. zero padding (multiple of kEnergyPD)
+  int n_real;               // real-table pair groups incl. zero padding (multiple of energy_pd(n))
   // register path (10 <= n <= 13): the state is handed to the energy step in the CANONICAL index
   // p' = M p (GF(2)-linear, chosen by the host so that the X mask of every real group touches one
   // of the R register bits LT..n-1 of p'); masks and tables below are expressed in p'.
-  int n_cls;                // leading real groups whose x' has a register bit (multiple of kEnergyPD)
+  int n_cls;                // leading real groups whose x' has a register bit (multiple of energy_pd(n))
   uint32_t mrow[16];        // row i of M: bit i of p' = parity(mrow[i] & p)
   // streaming path (n >= 14): explicit terms
   int n_terms;              // terms of the groups above
@@ -807,7 +807,9 @@ __device__ __forceinline__ void load_init(const Lds& L, const double2* init) {
 // multiple of PD] [groups with an imaginary table].  Table values stream from L2 through a
 // PD-deep register ring (group g+PD is requested when group g is consumed); the PD-unrolled
 // body is branch free so LDS reads of one group overlap the FMAs of the previous one.
-constexpr int kEnergyPD = 4;
+// (depth of the table ring by size: the shallower ring frees 32 registers where the kernel sits at its register cap -
+// n = 11 ... 13: +1..2 % - and costs 2..3 % where it does not)
+__host__ __device__ constexpr int energy_pd(int n) { return n >= 11 ? 2 : 4; }
 
 // All pairs of one group, both members read from LDS in batches of kEnergyBatch pairs (all
 // reads of a batch are in flight together, then the arithmetic).  DEXPR yields D for pair k
@@ -851,7 +853,7 @@ constexpr int kEnergyBatch = 4;
     VQE_ENERGY_PAIRS(x, hb, D[k])                                                                  \
   }
 
-// Real-table groups [g0, g1) (g1 - g0 a multiple of kEnergyPD, tables contiguous) with BOTH
+// Real-table groups [g0, g1) (g1 - g0 a multiple of energy_pd(n), tables contiguous) with BOTH
 // members of every pair read from LDS.
 template <int N>
 __device__ __forceinline__ void energy_real_lds(const Lds& L, const double* __restrict__ tables, int g0, int g1,
@@ -861,7 +863,7 @@ __device__ __forceinline__ void energy_real_lds(const Lds& L, const double* __re
   constexpr int NP = (DIM / 2 + kThreads - 1) / kThreads;   // pairs per thread
   constexpr int LT = Geo<N>::LT;
   constexpr int KB = N > LT + 1 ? N - LT - 1 : 0;           // log2(NP)
-  constexpr int PD = kEnergyPD;
+  constexpr int PD = energy_pd(N);
   constexpr bool FULL = DIM / 2 >= kThreads;                // every thread owns NP pairs
   const uint32_t tid = threadIdx.x;
   const unsigned char* psi_b = (const unsigned char*)L.psi;
@@ -1095,7 +1097,7 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H, Hook
   constexpr int NA = 1 << R;
   constexpr int NP = NA / 2;
   constexpr int HP = NP / 2;                 // pairs per half group
-  constexpr int PD = kEnergyPD;
+  constexpr int PD = energy_pd(N);
   static_assert(NP >= 2 && NP <= 8 && PD % 2 == 0, "register energy path: 2..8 pairs per thread");
   uint32_t tid = threadIdx.x;
   asm volatile("" : "+v"(tid));   // opaque: address terms derived from it are rebuilt per evaluation, not kept live across the kernel
