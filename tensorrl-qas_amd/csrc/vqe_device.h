@@ -72,12 +72,15 @@ constexpr int kOneWaveMaxQubits = VQE_ONE_WAVE_MAX;
 __host__ __device__ constexpr bool geo_one_wave(int n) { return n <= kOneWaveMaxQubits || (VQE_ONE_WAVE_REG && n == 10); }
 __host__ __device__ constexpr int geo_lt(int n) { return n >= kWideMinQubits ? 9 : (geo_one_wave(n) ? 6 : 8); }
 
+#ifndef VQE_WPS11
+#define VQE_WPS11 3     // n = 11: 170 registers per wave instead of 128 (464 B of spills), three workgroups per CU (the LDS rarely admits a fourth): +2..3 %
+#endif
 template <int N>
 struct Geo {
   static constexpr int NT = 1 << geo_lt(N);        // threads per workgroup
   static constexpr int LT = geo_lt(N);             // log2(NT)
   static constexpr int NW = NT / 64;               // waves per workgroup
-  static constexpr int WPS = (N <= 11 && !(VQE_ONE_WAVE_REG && N == 10)) ? 4 : 2;      // waves per SIMD asked of the register allocator
+  static constexpr int WPS = N == 11 ? VQE_WPS11 : ((N <= 10 && !(VQE_ONE_WAVE_REG && N == 10)) ? 4 : 2);      // waves per SIMD asked of the register allocator
 };
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
