@@ -72,6 +72,12 @@ constexpr int kOneWaveMaxQubits = VQE_ONE_WAVE_MAX;
 __host__ __device__ constexpr bool geo_one_wave(int n) { return n <= kOneWaveMaxQubits || (VQE_ONE_WAVE_REG && n == 10); }
 __host__ __device__ constexpr int geo_lt(int n) { return n >= kWideMinQubits ? 9 : (geo_one_wave(n) ? 6 : 8); }
 
+#ifndef VQE_WPS_SMALL
+#define VQE_WPS_SMALL 2     // n <= 9 (one wave per environment): all 256 registers - at 128 these kernels spilled 470..690 B per lane; eight environments per CU without spills beat sixteen with them by 18..32 %
+#endif
+#ifndef VQE_WPS10
+#define VQE_WPS10 4
+#endif
 #ifndef VQE_WPS11
 #define VQE_WPS11 3     // n = 11: 170 registers per wave instead of 128 (464 B of spills), three workgroups per CU (the LDS rarely admits a fourth): +2..3 %
 #endif
@@ -80,7 +86,7 @@ struct Geo {
   static constexpr int NT = 1 << geo_lt(N);        // threads per workgroup
   static constexpr int LT = geo_lt(N);             // log2(NT)
   static constexpr int NW = NT / 64;               // waves per workgroup
-  static constexpr int WPS = N == 11 ? VQE_WPS11 : ((N <= 10 && !(VQE_ONE_WAVE_REG && N == 10)) ? 4 : 2);      // waves per SIMD asked of the register allocator
+  static constexpr int WPS = N == 11 ? VQE_WPS11 : (N == 10 ? (VQE_ONE_WAVE_REG ? 2 : VQE_WPS10) : (N <= 9 ? VQE_WPS_SMALL : 2));      // waves per SIMD asked of the register allocator
 };
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
