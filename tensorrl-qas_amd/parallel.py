@@ -43,13 +43,18 @@ def term_owner(n_qubits: int, xmask, world: int) -> np.ndarray:
 
 
 def allreduce_sum(values, group=None):
-    """Sum a float64 tensor (or array) of partial energies over all ranks, in place."""
+    """Sum a float64 tensor (or array) of partial energies over all ranks, in place.
+
+    Device tensors go to RCCL as they are (backend "nccl"); host values under RCCL travel through this rank's
+    GPU.  Under gloo (CPU tests, the two-ranks-on-one-GPU test) a device tensor is summed through a host copy:
+    gloo's own device path (pinned staging buffers filled by its worker threads) is never entered."""
     import torch
     import torch.distributed as dist
     t = values if isinstance(values, torch.Tensor) else torch.as_tensor(np.asarray(values, np.float64))
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        if not t.is_cuda and dist.get_backend(group) == "nccl":      # host values under RCCL: via this rank's GPU
-            d = t.to(torch.device("cuda", torch.cuda.current_device()))
+        nccl = dist.get_backend(group) == "nccl"
+        if t.is_cuda != nccl:
+            d = t.to(torch.device("cuda", torch.cuda.current_device())) if nccl else t.cpu()
             dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
             t.copy_(d)
         else:
@@ -87,33 +92,38 @@ class TermShardedEngine:
             engine.set_amplitude_shard(rank, world)
         else:
             engine.set_term_shard(rank, world)
+        # ONE stream for the engine's launches, the device-to-device copy and the collective: a torch stream of
+        # this object's own that the handle is told to issue on (vqe_set_stream), so inside energies() plain stream
+        # order is all the ordering there is; the caller's current stream is ordered against it once on the way
+        # in and once on the way out, with torch's own wait_stream on torch's own streams.  (torch's DEFAULT stream
+        # cannot be handed to the handle: its pointer is NULL, which vqe_set_stream reads as "your own stream" -
+        # a non-blocking one that the default stream does not order against.  Round 2 wrapped the handle's stream
+        # in torch.cuda.ExternalStream instead; that code is gone.)
+        with torch.cuda.device(self.device):
+            self._stream = torch.cuda.Stream(device=self.device)
+        engine.set_stream(self._stream.cuda_stream)
         self._buf = None
 
-    def _streams(self):
-        """(torch's current stream, the engine's stream wrapped for torch) or None when both are
-        the same stream.  The engine launches on its own HIP stream unless ``set_stream`` handed it
-        torch's; the all-reduce runs on torch's stream, so the two have to be ordered explicitly."""
-        import torch
-        cur = torch.cuda.current_stream(self.device)
-        ptr = self.engine.get_stream()
-        if ptr == cur.cuda_stream:
-            return None
-        return cur, torch.cuda.ExternalStream(ptr, device=self.device)
+    def close(self):
+        """Give the handle its own stream back (after draining this object's) and drop the result buffer."""
+        if self.engine is not None:
+            self._stream.synchronize()
+            self.engine.set_stream(None)
+            self.engine, self._buf = None, None
 
     def energies(self, batch: int):
         import torch
-        st = self._streams()
-        if self._buf is None or self._buf.numel() != batch:
-            self._buf = torch.zeros(batch, dtype=torch.float64, device=self.device)
-            if st is not None:
-                st[1].wait_stream(st[0])      # the fill lands before the engine's copy
-        elif st is not None:
-            st[1].wait_stream(st[0])          # the previous all-reduce has read the buffer
-        self.engine.batch_run_energy()
-        self.engine.batch_copy_energy(self._buf.data_ptr())
-        if st is not None:
-            st[0].wait_stream(st[1])          # the all-reduce starts after the copy
-        return allreduce_sum(self._buf)
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)             # whatever the caller still does with the previous result
+        with torch.cuda.stream(self._stream):
+            if self._buf is None or self._buf.numel() != batch:
+                self._buf = torch.zeros(batch, dtype=torch.float64, device=self.device)
+            self.engine.batch_run_energy()
+            self.engine.batch_copy_energy(self._buf.data_ptr())
+            out = allreduce_sum(self._buf)
+        cur.wait_stream(self._stream)             # the caller reads the sum on its own stream
+        out.record_stream(cur)
+        return out
 
     def partial_energies(self):
         """This rank's share of the energies of the resident batch (host array, not reduced)."""

@@ -405,15 +405,17 @@ def test_device_cobyla_trajectory(tq, n, P, seed):
 
 # ---- streaming path: env-step and a 20-qubit CircuitEnv end to end --------------------------------
 def test_streaming_env_step_semantics(tq):
-    """vqe_batch_run_env_step at n = 14 (host-driven COBYLA over batched evaluations): COBYLA sees the
-    circuit WITHOUT the new gate, the result is rounded to float32, f is the energy of the full circuit -
-    the library's host COBYLA driven by oracle energies of the pre-action circuit must walk the same
-    trial points while the cost is smooth (same source, same summation order: bit-exact build)."""
+    """vqe_batch_run_env_step at n = 14: COBYLA sees the circuit WITHOUT the new gate, the result is rounded to
+    float32, f is the energy of the full circuit.  The optimiser phase is pinned exactly: the library's host COBYLA
+    (bit-exact with scipy, tests/test_abi.py) driven by THIS engine's energies of the pre-action circuit walks the
+    same trial points, bit for bit, to the same result (same optimiser source, same energy kernels, fixed-order
+    reductions); every one of those energies is checked against the oracle to 1e-10 on the way."""
     n = 14
     rng = np.random.default_rng(1414)
     psi0 = random_state(n, rng)
     ham = random_hamiltonian(n, 20, rng)
     eng = _engine(tq, n, psi0, ham)
+    eng1 = _engine(tq, n, psi0, ham)        # single-circuit evaluations of the pre-action circuits
     raw, circs, ths, new = [], [], [], []
     for b in range(3):
         g = list(_tie_free_gates(n, 4 + b, rng))
@@ -445,11 +447,19 @@ def test_streaming_env_step_semantics(tq):
                 assert xb[hole] == th[hole] == 0.0
         sel = [j for j in range(P) if j != hole]
         pp = np.where(pidx[keep] > hole, pidx[keep] - 1, pidx[keep]) if hole >= 0 else pidx[keep]
-        cost = lambda t: vo.energy_pauli(vo.run_circuit(psi0, kind[keep], q0[keep], q1[keep], pp, t), *ham)
+        pre = tq.Circuit(kind[keep], q0[keep], q1[keep], pp, len(sel))
+        eng1.set_circuit(pre)
+        worst = [0.0]
+
+        def cost(t):
+            e = eng1.energy(t)
+            ref = vo.energy_pauli(vo.run_circuit(psi0, kind[keep], q0[keep], q1[keep], pp, t), *ham)
+            worst[0] = max(worst[0], abs(e - ref))
+            return e
+
         xh, fh, nh, _ = tq.HostCobyla(th[sel], 1.0, 1e-4, 60).minimize(cost)
-        # (energies of the two sides differ in the last bits, so the runs drift apart late: same optimum, not same bits)
-        assert nfev[b] == nh == 60 and np.abs(xr[sel] - xh).max() < 5e-2 and abs(cost(xr[sel]) - fh) < 1e-4, \
-            (b, nfev[b], nh, np.abs(xr[sel] - xh).max(), cost(xr[sel]) - fh)
+        assert worst[0] < E_TOL
+        assert nfev[b] == nh and np.array_equal(xr[sel], xh), (b, nfev[b], nh, np.abs(xr[sel] - xh).max())
 
 
 def test_heisenberg_20q_circuit_env_episode(tmp_path):
@@ -485,7 +495,7 @@ def test_heisenberg_20q_circuit_env_episode(tmp_path):
         assert abs(env.energy - e_ref) < E_TOL, (step, env.energy, e_ref)
         assert abs(env.error - abs(E0 - e_ref)) < 1e-9 and done == 0
         assert abs(float(rwd) - np.float32(np.clip((prev - env.energy) / abs(prev - E0), -1, 1))) < 1e-6
-    assert env.nfev >= 1 and env.energy <= e_init + 1e-6 or True
+    assert 1 <= env.nfev <= 25 and E0 - 1e-9 <= env.energy <= 39.0 + 1e-9
     # the batched host loop on the same path
     vec = VecCircuitEnv(CircuitEnv, conf, torch.device("cuda:0"), 3)
     vec.reset()

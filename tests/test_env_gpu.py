@@ -299,63 +299,6 @@ def test_vec_env_async_halves_equal_plain_steps(data_root):
             assert torch.equal(o, out[h][t][0]) and torch.equal(r, out[h][t][1]) and d == out[h][t][2]
 
 
-def _sharded_worker(rank, world, port, out):
-    import os
-    import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    sys.path.insert(0, here)
-    sys.path.insert(0, os.path.join(os.path.dirname(here), "oracle"))
-    import tensorrl_qas_amd as tq
-    from tensorrl_qas_amd import parallel
-    from helpers import random_gates, random_hamiltonian, random_state
-    res = {}
-    for n, by_amp in ((12, False), (14, True), (14, False)):
-        rng = np.random.default_rng(n)
-        psi0 = random_state(n, rng)
-        ham = random_hamiltonian(n, 30, rng)
-        kind, q0, q1, pidx, th = random_gates(n, 10, rng)
-        eng = tq.VQEEngine(n, 0)            # both ranks share the one GPU of the test box
-        eng.set_init_state(psi0)
-        eng.set_hamiltonian(*ham)
-        circ = tq.Circuit(kind, q0, q1, pidx, th.size)
-        sh = parallel.TermShardedEngine(eng, rank, world, "cuda:0", by_amplitude=by_amp)
-        eng.batch_load([circ], [th])
-        e = float(sh.energies(1)[0].item())
-        x, f, nfev, status = sh.minimize(circ, th, 1.0, 1e-4, 40)
-        res[(n, by_amp)] = dict(e=e, x=np.asarray(x).tolist(), f=float(f), nfev=int(nfev))
-    out[rank] = res
-    dist.destroy_process_group()
-
-
-def test_term_sharded_engine_two_ranks_on_one_gpu():
-    """world_size 2 (gloo, both ranks on cuda:0): all-reduced energies equal the unsharded energy,
-    the lock-step sharded COBYLA returns the same x / f / nfev on both ranks, and f is the
-    (unscaled) energy at x."""
-    import socket
-    import torch.multiprocessing as mp
-    import vqe_oracle as vo
-    from helpers import random_gates, random_hamiltonian, random_state
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    with mp.Manager() as m:
-        out = m.dict()
-        mp.spawn(_sharded_worker, args=(2, port, out), nprocs=2, join=True)
-        r0, r1 = dict(out[0]), dict(out[1])
-    for key in r0:
-        n, _ = key
-        rng = np.random.default_rng(n)
-        psi0 = random_state(n, rng)
-        ham = random_hamiltonian(n, 30, rng)
-        kind, q0, q1, pidx, th = random_gates(n, 10, rng)
-        assert r0[key] == r1[key]
-        assert abs(r0[key]["e"] - vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th), *ham)) < 1e-10
-        x = np.array(r0[key]["x"])
-        assert abs(r0[key]["f"] - vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, x), *ham)) < 1e-10
-        assert 1 <= r0[key]["nfev"] <= 40
-
-
 def test_lower_seam_vqa_shim():
     """The reference's L2 seam names (environments/VQAs/VQE_qulacs_TN_notin_RL.py and the
     from-|0> twin VQE_qulacs.py): construct_ansatz / get_exp_val / get_energy_qulacs on a state
