@@ -96,7 +96,7 @@ enum Status { RUNNING = 0, DONE_RHOEND = 1, DONE_MAXFUN = 2, DONE_ROUNDING = 3 }
 
 // Scalars of the optimiser, parked behind the arrays between two calls (save_state /
 // load_state) so that a device kernel holds none of them in registers while it evaluates f.
-constexpr int kStateDoubles = 14;
+constexpr int kStateDoubles = 15;
 
 // Leading dimension of sim / simi: odd, so that walking a matrix along either index touches
 // distinct LDS banks (a stride of n doubles with n = 32 puts a whole column in one bank).
@@ -174,14 +174,14 @@ struct CobylaM0 {
     if (ctx.tid == 0) {
       st[0] = rho; st[1] = prerem; st[2] = parsig; st[3] = pareta; st[4] = fbest_ret; st[5] = rhoend;
       st[6] = (double)nfvals; st[7] = (double)jdrop; st[8] = (double)ibrnch; st[9] = (double)iflag;
-      st[10] = (double)ifull; st[11] = (double)status; st[12] = (double)maxfun; st[13] = (double)(vcol + 2 + 1024 * (vrow + 2));
+      st[10] = (double)ifull; st[11] = (double)status; st[12] = (double)maxfun; st[13] = (double)vcol; st[14] = (double)vrow;
     }
     ctx.sync();
   }
   CBY_HD void load_state() {
     rho = st[0]; prerem = st[1]; parsig = st[2]; pareta = st[3]; fbest_ret = st[4]; rhoend = st[5];
     nfvals = (int)st[6]; jdrop = (int)st[7]; ibrnch = (int)st[8]; iflag = (int)st[9];
-    ifull = (int)st[10]; status = (int)st[11]; maxfun = (int)st[12]; { const int pk = (int)st[13]; vcol = pk % 1024 - 2; vrow = pk / 1024 - 2; }
+    ifull = (int)st[10]; status = (int)st[11]; maxfun = (int)st[12]; vcol = (int)st[13]; vrow = (int)st[14];
   }
 
   // Begin a minimisation; x[] must already hold x0.  Returns 1 when f(x) is wanted.

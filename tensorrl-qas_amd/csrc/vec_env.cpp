@@ -255,22 +255,32 @@ int vqe_vecenv_step_begin(vqe_vecenv_t* v, const int32_t* actions) {
   v->gate_off.assign(1, 0); v->par_off.assign(1, 0);
   v->kind.clear(); v->q0.clear(); v->q1.clear(); v->pidx.clear(); v->theta.clear();
   v->new_gate.assign(B, -1);
+  // pass 1: every action of the batch is validated before ANY environment is touched - a rejected call leaves all B
+  // environments exactly as they were (a caller that catches the error may correct the action and step again)
   for (int b = 0; b < B; ++b) {
-    Env& e = v->env[b];
+    const Env& e = v->env[b];
     const int32_t* a = actions + 4 * (size_t)b;
     const int ctrl = a[0], rot_qubit = a[2], rot_axis = a[3];
     if (ctrl < 0 || ctrl > n || a[1] < 0 || rot_qubit < 0 || rot_qubit > n || (rot_qubit < n && (rot_axis < 1 || rot_axis > 3)) ||
         (ctrl >= n && rot_qubit >= n))
       return fail(v, VQE_EINVAL, "action places no gate / is out of range");
     const int targ = (ctrl + a[1]) % n;
+    const int gate_tensor = rot_qubit < n ? e.moments[rot_qubit] : std::max(e.moments[ctrl], e.moments[targ]);
+    if (v->cfg.layer_offset + gate_tensor >= L) return fail(v, VQE_EINVAL, "action beyond the last layer of the state tensor");
+    if (ctrl < n && targ == ctrl) return fail(v, VQE_EINVAL, "CNOT with control == target");
+  }
+  // pass 2: the bookkeeping of step() (no failure path from here to the engine calls)
+  for (int b = 0; b < B; ++b) {
+    Env& e = v->env[b];
+    const int32_t* a = actions + 4 * (size_t)b;
+    const int ctrl = a[0], rot_qubit = a[2], rot_axis = a[3];
+    const int targ = (ctrl + a[1]) % n;
     e.step_counter += 1;                                                     // (:241)
     const bool is_rot = rot_qubit < n;                                       // the layer follows the rotation when both are set (:260-263)
     const int gate_tensor = is_rot ? e.moments[rot_qubit] : std::max(e.moments[ctrl], e.moments[targ]);
     const int layer = v->cfg.layer_offset + gate_tensor;
-    if (layer >= L) return fail(v, VQE_EINVAL, "action beyond the last layer of the state tensor");
     // what the action writes: a CNOT when ctrl < n, else the rotation (:265-268)
     Gate g{layer, (int8_t)(ctrl < n ? 0 : rot_axis), (int8_t)(ctrl < n ? ctrl : rot_qubit), (int8_t)(ctrl < n ? targ : -1), 0.0f};
-    if (ctrl < n && targ == ctrl) return fail(v, VQE_EINVAL, "CNOT with control == target");
     auto it = std::lower_bound(e.gates.begin(), e.gates.end(), g, [](const Gate& x, const Gate& y) { return x.key() < y.key(); });
     e.new_pos = -1;
     e.obs_index = -1;
@@ -325,6 +335,7 @@ int vqe_vecenv_step_end(vqe_vecenv_t* v, int train_flag, float* reward, int32_t*
   int rc = vqe_batch_fetch(v->eng, v->x.data(), v->f.data(), v->nfev.data());
   if (!rc) rc = vqe_batch_fetch_xopt(v->eng, v->xraw.data());
   if (rc) return fail(v, rc, std::string("engine: ") + vqe_last_error(v->eng));
+  bool curriculum_exhausted = false;
   for (int b = 0; b < B; ++b) {
     Env& e = v->env[b];
     const double* xb = v->x.data() + v->par_off[b];
@@ -354,8 +365,8 @@ int vqe_vecenv_step_end(vqe_vecenv_t* v, int train_flag, float* reward, int32_t*
       e.episodes_completed += 1;
       bool ok;
       const double t = current_threshold(v, e.episodes_completed, &ok);
-      if (!ok) return fail(v, VQE_ESTATE, "curriculum: no threshold left for this episode count");
-      e.done_threshold = t;
+      if (!ok) curriculum_exhausted = true;      // reported after the loop: every environment finishes its step first
+      else e.done_threshold = t;
       e.episodes_completed_saved = e.episodes_completed;
       e.lowest_energy_saved = e.lowest_energy;
     }
@@ -363,6 +374,7 @@ int vqe_vecenv_step_end(vqe_vecenv_t* v, int train_flag, float* reward, int32_t*
     done[b] = d;
     if (obs_index) obs_index[b] = e.obs_index;
   }
+  if (curriculum_exhausted) return fail(v, VQE_ESTATE, "curriculum: no threshold left for this episode count");
   return VQE_OK;
 }
 

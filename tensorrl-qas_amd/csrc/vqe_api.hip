@@ -402,9 +402,12 @@ int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
   // 256-thread workgroups below the register path (n = 9 by default) with more than 64 parameters in a circuit (the
   // trainable regime): the variant whose optimiser update runs on the whole workgroup (StagedCobyla<N, WIDE>).
   // One-wave workgroups (n <= kOneWaveMaxQubits) have no second wave to spread it over.
-  constexpr bool kHasWide = Geo<N>::NT >= 256 && N >= 6;
+  // One-wave workgroups (n <= kOneWaveMaxQubits) can run that variant too (VQE_WIDE64=1; round 2's attempt hung on an
+  // uninitialised pointer, see StagedCobyla::call): off by default until it measures faster than the one-wave context.
+  constexpr bool kHasWide = N >= 6;
   static const bool wide_on = [] { const char* e = std::getenv("VQE_WIDE_UPDATE"); return !(e && e[0] == '0'); }();   // A/B knob
-  const bool wide = kHasWide && wide_on && which == 1 && A.max_params > 64;
+  static const bool wide64_on = [] { const char* e = std::getenv("VQE_WIDE64"); return e && e[0] == '1'; }();
+  const bool wide = kHasWide && wide_on && which == 1 && A.max_params > 64 && (Geo<N>::NT >= 256 || wide64_on);
   const bool noisy = A.noise.p1 > 0.0 || A.noise.p2 > 0.0;
   constexpr bool kW = false;     // up to 64 parameters per circuit: the instantiation without the workgroup-wide update
   const void* fn = which == 0 ? (const void*)k_lds_energy<N>

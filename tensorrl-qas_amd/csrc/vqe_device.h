@@ -1270,7 +1270,6 @@ struct NoSide { __device__ __forceinline__ void operator()() const {} };
 template <int N, bool WIDE = (N >= 10 && Geo<N>::NT >= 256)>
 struct StagedCobyla {
   static constexpr int kThreads = Geo<N>::NT;
-  static_assert(!WIDE || kThreads >= 256, "the workgroup-wide update wants several waves (a one-wave instantiation hung on the GPU in round 2)");
   typedef cby::CobylaM0<WaveCtx, false, lds_double> CobL;   // arrays in LDS (ds_ instructions)
   typedef cby::CobylaM0<WaveCtx, false, double> CobG;       // arrays in the global scratch, one wave
   typedef cby::CobylaM0<BlockCtx<Geo<N>::NT>, false, double> CobB;   // the same, whole workgroup (more rows than a wave has lanes)
@@ -1361,7 +1360,10 @@ struct StagedCobyla {
   __device__ __forceinline__ void call(Ptr mem, double f, double rhobeg, double rhoend, int maxfun) {
     Cob cob;
     cob.ctx.tid = Cob::P == 0 ? 0 : (int)(threadIdx.x % (unsigned)decltype(cob.ctx)::nth);
-    if constexpr (decltype(cob.ctx)::nth != 64) cob.ctx.red = red;
+    // the workgroup contexts reduce through LDS words.  (Round 2 tested `nth != 64` here to tell them from WaveCtx:
+    // BlockCtx<64> has 64 threads too, so a one-wave instantiation of the workgroup-wide update ran arg_first / all_or
+    // through an UNINITIALISED `red` pointer - the "hang" recorded in round 2)
+    if constexpr (!std::is_same<decltype(cob.ctx), WaveCtx>::value) cob.ctx.red = red;
     // opaque copies: otherwise the array addresses bind() derives are loop invariants of the
     // evaluation loop, get hoisted out of it, spilled across the energy step (where registers
     // are scarcest) and reloaded from scratch inside every tell()

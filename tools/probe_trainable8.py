@@ -20,6 +20,6 @@ eng.batch_load_flat(np.arange(B + 1, dtype=np.int64) * G, kind.ravel(), q0.ravel
 eng.batch_run_minimize(1.0, 1e-4, mf); eng.sync()
 eng.batch_run_minimize(1.0, 1e-4, mf); eng.sync()
 ms = eng.last_kernel_ms(); x, f, nfev = eng.batch_fetch()
-print(f"n=8 G={G} mean P={rot.sum(1).mean():.0f} B={B}: {ms:.1f} ms, {nfev.sum()/ms*1e-3:.2f} M evals/s, {B/ms*1e3:.0f} env-steps/s at maxfun {mf}")
+print(f"n=8 G={G} mean P={rot.sum(1).mean():.0f} B={B}: {ms:.1f} ms, {nfev.sum()/ms*1e-3:.2f} M evals/s, {B/ms*1e3:.0f} env-steps/s at maxfun {mf}; mean f {f.mean():.9f} min {f.min():.9f} mean nfev {nfev.mean():.1f}")
 c = eng.debug_counters().astype(float)
 if c[0] > 0: print(f"  per eval cycles: circuit {c[1]/c[0]:.0f} energy {c[2]/c[0]:.0f} tell {c[3]/c[0]:.0f}")
