@@ -83,6 +83,14 @@ int vqe_set_hamiltonian_pauli(vqe_t* h, int n_terms, const uint64_t* xmask,
  * was found. */
 int vqe_set_hamiltonian_dense(vqe_t* h, const double* op_re_im /* 2 * 4^n */, double tol);
 int vqe_hamiltonian_terms(vqe_t* h, int32_t* n_terms, int32_t* n_xgroups);
+/* How the LDS-resident kernels hold this handle's share of the Hamiltonian (diagnostic; n <= 13):
+ * out[0] = X-mask groups evaluated through full sign-sum tables, out[1] = units - sub-cubes of
+ * one pair per thread on which the table of a mostly-zero group (a fermionic excitation operator
+ * connects one occupation pattern in 2^w) does not vanish; groups stored as units are not in
+ * out[0] -, out[2] = groups of out[0] whose partner index sits in the register bits, out[3] = 1
+ * if there is a diagonal group.  The reference has no counterpart: its get_exp_val multiplies
+ * by the dense matrix (VQE_qulacs_TN_notin_RL.py:86). */
+int vqe_hamiltonian_layout(vqe_t* h, int32_t out[4]);
 /* Evaluate only the X-mask groups owned by `rank` of `world` (Pauli-term sharding; the
  * caller sums the partial energies of all ranks, e.g. one RCCL all-reduce). */
 int vqe_set_term_shard(vqe_t* h, int rank, int world);

@@ -60,6 +60,8 @@ struct vqe_handle {
   DevBuf<int32_t> d_tab_r, d_tab_i;
 
   DevBuf<int32_t> d_term_off;
+  DevBuf<uint32_t> d_urec;   // unit path (HamDev::urec / utab)
+  DevBuf<double> d_utab;
   HamDev ham{};
   NoiseCfg noise{0.0, 0.0, 0ull, 0ull, 0.0};
 
@@ -228,6 +230,99 @@ IndexMap choose_index_map(int n, int lt, const std::vector<uint32_t>& xs) {
   return m;
 }
 
+// ---- unit path: X-mask groups with mostly-zero sign-sum tables -------------------------------------
+// The sign-sum table D_x(p) = sum_k c_k (-1)^{popc(p & z_k)} of a fermionic excitation operator vanishes EXACTLY on
+// every pair {p, p^x} whose occupation pattern the operator does not connect (a hopping pair XZ..ZX + YZ..ZY acts on
+// 01 <-> 10 only, a double-excitation octet on one pattern pair in eight): 76 % of the entries of the bench
+// Hamiltonian, 69 % of the shipped H2O one.  A group is cut into sub-cubes of NT pairs (fix F = n-1-LT index bits
+// besides the selector bit); only sub-cubes on which D does not vanish become *units* (HamDev::urec).
+// Entries below kUnitZeroTol x sum_k |c_k| are rounding residues of sums that cancel exactly in real arithmetic
+// (3w - w - w - w is not 0 in floating point) and count as zero.
+constexpr double kUnitZeroTol = 0x1p-44;       // 5.7e-14 relative: far above the residues (~1e-16), far below any term
+
+// a permutation of the qubits as canonical index map: position lt.. (the register bits of the class path) cover
+// the masks of the dense groups, the other qubits are placed by how often they are a fixed / selector bit of a
+// unit - the most frequent ones highest, so that the lowest index bits (consecutive lanes, LDS banks) stay free
+IndexMap choose_permutation(int n, int lt, const std::vector<uint32_t>& dense_xs, const std::vector<int>& hole_freq) {
+  IndexMap m;
+  m.n = n;
+  std::vector<int> at(n, -1);            // qubit at canonical position i
+  std::vector<bool> used(n, false);
+  std::vector<uint32_t> rem(dense_xs);
+  for (int pos = n - 1; pos >= 0; --pos) {
+    int best = -1;
+    if (pos >= lt && !rem.empty()) {
+      int best_hits = 0;
+      for (int q = 0; q < n; ++q) {
+        if (used[q]) continue;
+        int hits = 0;
+        for (uint32_t x : rem) hits += (x >> q) & 1u;
+        if (hits > best_hits) { best_hits = hits; best = q; }
+      }
+      if (best >= 0) {
+        std::vector<uint32_t> keep;
+        for (uint32_t x : rem) if (!((x >> best) & 1u)) keep.push_back(x);
+        rem.swap(keep);
+      }
+    }
+    if (best < 0)
+      for (int q = n - 1; q >= 0; --q)
+        if (!used[q] && (best < 0 || hole_freq[q] > hole_freq[best])) best = q;
+    used[best] = true;
+    at[pos] = best;
+  }
+  for (int i = 0; i < n; ++i) m.row[i] = m.inv_col[i] = 1u << at[i];
+  return m;
+}
+
+// sign-sum table of a real group over pair representatives p0 = insert0(q, sel) in the index space of `im`
+// (factor 2 of the pair symmetry included, as in the pair tables of the group lists)
+void pair_table(const vqe_t* h, int g, const IndexMap& im, int n, int sel, std::vector<double>& D, double* scale) {
+  const size_t len = (size_t)1 << (n - 1);
+  D.assign(len, 0.0);
+  *scale = 0.0;
+  for (int k : h->group_terms[g]) {
+    const uint32_t z = im.map_z((uint32_t)h->hz[k]);
+    const double c = 2.0 * h->hcr[k];
+    *scale += std::fabs(c);
+    for (size_t q = 0; q < len; ++q) {
+      const uint32_t p0 = (uint32_t)(((q >> sel) << (sel + 1)) | (q & (((size_t)1 << sel) - 1)));
+      D[q] += (__builtin_popcount(p0 & z) & 1) ? -c : c;
+    }
+  }
+}
+
+// Fixed bits of a group's units: greedily the index bits (not the selector) on which the active pairs agree most;
+// stops when no bit helps any more (every remaining one doubles the number of active patterns).  Returns the
+// number of active patterns on `fixed`; the units of the group are patterns x 2^(F - |fixed|) (filler bits).
+int choose_fixed_bits(int n, int sel, int F, const std::vector<uint32_t>& act, std::vector<int>& fixed) {
+  fixed.clear();
+  if (act.empty()) return 0;
+  int patterns = 1;
+  auto count = [&](int extra) {
+    uint32_t seen = 0;
+    for (uint32_t p0 : act) {
+      uint32_t key = 0;
+      for (size_t i = 0; i < fixed.size(); ++i) key |= ((p0 >> fixed[i]) & 1u) << i;
+      key |= ((p0 >> extra) & 1u) << fixed.size();
+      seen |= 1u << key;
+    }
+    return __builtin_popcount(seen);
+  };
+  while ((int)fixed.size() < F) {
+    int best = -1, best_cnt = 1 << 30;
+    for (int b = n - 1; b >= 0; --b) {
+      if (b == sel || std::find(fixed.begin(), fixed.end(), b) != fixed.end()) continue;
+      const int c = count(b);
+      if (c < best_cnt) { best_cnt = c; best = b; }
+    }
+    if (best < 0 || best_cnt >= 2 * patterns) break;
+    fixed.push_back(best);
+    patterns = best_cnt;
+  }
+  return patterns;
+}
+
 // Build (or rebuild after re-sharding) the device Hamiltonian.
 int build_hamiltonian(vqe_t* h) {
   const int n = h->n;
@@ -254,10 +349,113 @@ int build_hamiltonian(vqe_t* h) {
   const bool reg_path = h->lds_path && n >= kRegMinQubits;
   const int lt = geo_lt(n);                        // Geo<N>::LT of the register path
   IndexMap im = identity_map(n);
-  if (reg_path) {
+  // unit path (register path only): pass 1 in the qubit order as given - which groups are sparse, which qubits are
+  // their fixed / selector bits
+  const int unit_F = n - 1 - lt;
+  static const bool units_on = [] { const char* e = std::getenv("VQE_UNITS"); return !(e && e[0] == '0'); }();   // A/B knob
+  std::vector<char> sparse(h->gx_all.size(), 0);
+  bool any_sparse = false;
+  if (reg_path && units_on && unit_F >= 1) {
+    std::vector<int> hole_freq(n, 0);
+    std::vector<uint32_t> dense_xs;
+    std::vector<double> D;
+    std::vector<uint32_t> act;
+    std::vector<int> fixed;
+    for (int g : mine) {
+      const uint32_t x = h->gx_all[g];
+      if (!x || group_has_im(g)) continue;
+      const int sel = 31 - __builtin_clz(x);
+      double scale;
+      pair_table(h, g, im, n, sel, D, &scale);
+      act.clear();
+      for (size_t q = 0; q < D.size(); ++q)
+        if (std::fabs(D[q]) > kUnitZeroTol * scale)
+          act.push_back((uint32_t)(((q >> sel) << (sel + 1)) | (q & (((size_t)1 << sel) - 1))));
+      const int patterns = choose_fixed_bits(n, sel, unit_F, act, fixed);
+      const int units = patterns << (unit_F - (int)fixed.size());
+      // a unit costs 2 LDS reads, a group of the class path 2^(F+1) / 2: sparse when no more than half of its
+      // sub-cubes are active
+      if (2 * units <= (1 << unit_F)) {
+        sparse[g] = 1;
+        any_sparse = true;
+        for (int b : fixed) ++hole_freq[b];
+        ++hole_freq[sel];
+      } else {
+        dense_xs.push_back(x);
+      }
+    }
+    if (any_sparse) im = choose_permutation(n, lt, dense_xs, hole_freq);
+  }
+  if (reg_path && !any_sparse) {
     std::vector<uint32_t> xs;
     for (int g : mine) if (h->gx_all[g] && !group_has_im(g)) xs.push_back(h->gx_all[g]);
     im = choose_index_map(n, lt, xs);
+  }
+  // pass 2 in the canonical index space: the units themselves
+  std::vector<uint32_t> urec;
+  std::vector<double> utab;
+  if (any_sparse) {
+    const size_t NT = (size_t)1 << lt;
+    std::vector<double> D;
+    std::vector<uint32_t> act;
+    std::vector<int> fixed;
+    for (int g : mine) {
+      if (!sparse[g]) continue;
+      const uint32_t x = im.map_x(h->gx_all[g]);
+      const int sel = 31 - __builtin_clz(x);
+      double scale;
+      pair_table(h, g, im, n, sel, D, &scale);
+      auto rep = [&](size_t q) { return (uint32_t)(((q >> sel) << (sel + 1)) | (q & (((size_t)1 << sel) - 1))); };
+      act.clear();
+      for (size_t q = 0; q < D.size(); ++q) if (std::fabs(D[q]) > kUnitZeroTol * scale) act.push_back(rep(q));
+      choose_fixed_bits(n, sel, unit_F, act, fixed);
+      // filler bits: the highest positions that are neither fixed nor the selector
+      for (int b = n - 1; b >= 0 && (int)fixed.size() < unit_F; --b)
+        if (b != sel && std::find(fixed.begin(), fixed.end(), b) == fixed.end()) fixed.push_back(b);
+      uint32_t fmask = 0;
+      for (int b : fixed) fmask |= 1u << b;
+      uint32_t seen_keys[8];
+      int n_keys = 0;
+      for (uint32_t p0 : act) {       // distinct patterns of the fixed bits among the active pairs
+        const uint32_t key = p0 & fmask;
+        bool dup = false;
+        for (int i = 0; i < n_keys; ++i) dup |= seen_keys[i] == key;
+        if (!dup && n_keys < 8) seen_keys[n_keys++] = key;
+      }
+      std::sort(seen_keys, seen_keys + n_keys);
+      // deposit masks: the free positions between consecutive holes (holes = fixed bits + selector), byte addresses
+      std::vector<int> holes(fixed);
+      holes.push_back(sel);
+      std::sort(holes.begin(), holes.end());
+      uint32_t m[5] = {0, 0, 0, 0, 0};
+      for (size_t i = 0; i <= holes.size(); ++i) {
+        const int lo = i == 0 ? 0 : holes[i - 1] + 1, hi = i == holes.size() ? n : holes[i];
+        m[i] = (uint32_t)((((uint64_t)1 << hi) - ((uint64_t)1 << lo)) << 4);
+      }
+      for (int ki = 0; ki < n_keys; ++ki) {
+        const uint32_t s = seen_keys[ki];
+        const uint32_t toff = (uint32_t)(utab.size() * sizeof(double));
+        const uint32_t rec[8] = {m[0], m[1], m[2], m[3], m[4], s << 4, x << 4, toff};
+        urec.insert(urec.end(), rec, rec + 8);
+        for (size_t t = 0; t < NT; ++t) {
+          uint32_t p0 = s, tb = 0;       // deposit the bits of t into the free positions, ascending
+          for (int b = 0; b < n; ++b)
+            if (!((fmask >> b) & 1u) && b != sel) { p0 |= (uint32_t)((t >> tb) & 1u) << b; ++tb; }
+          const size_t q = ((size_t)(p0 >> (sel + 1)) << sel) | (p0 & (((size_t)1 << sel) - 1));
+          const double d = D[q];
+          utab.push_back(std::fabs(d) > kUnitZeroTol * scale ? d : 0.0);
+        }
+      }
+    }
+    if (utab.size() * sizeof(double) + (size_t)kUnitUnroll * NT * sizeof(double) > 0x7FFFFFFFu)
+      return fail(h, VQE_EINVAL, "Hamiltonian too large for the LDS-resident path");
+    // padding to a multiple of kUnitUnroll: units with a table of zeros (unit k owns table doubles [k NT, (k+1) NT):
+    // the kernel derives the offset from the unit index)
+    while ((urec.size() / 8) % kUnitUnroll) {
+      const uint32_t rec[8] = {0, 0, 0, 0, 0, 0, 0, (uint32_t)(utab.size() * sizeof(double))};
+      urec.insert(urec.end(), rec, rec + 8);
+      utab.resize(utab.size() + NT, 0.0);
+    }
   }
   auto gxm = [&](int g) { return im.map_x(h->gx_all[g]); };
   // section of a group: 0 diagonal, 1 real with a register bit in x' (register path only),
@@ -291,6 +489,7 @@ int build_hamiltonian(vqe_t* h) {
     cur_rank = rank;
   };
   for (int g : mine) {
+    if (sparse[g]) continue;         // lives in the unit list
     const uint32_t x = gxm(g);
     const bool has_im = group_has_im(g);
     const int rank = rank_of(g);
@@ -352,6 +551,8 @@ int build_hamiltonian(vqe_t* h) {
   if ((rc = upload(h, h->d_term_z, term_z.data(), term_z.size()))) return rc;
   if ((rc = upload(h, h->d_term_cr, term_cr.data(), term_cr.size()))) return rc;
   if ((rc = upload(h, h->d_term_ci, term_ci.data(), term_ci.size()))) return rc;
+  if ((rc = upload(h, h->d_urec, urec.data(), urec.size()))) return rc;
+  if ((rc = upload(h, h->d_utab, utab.data(), utab.size()))) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));  // host vectors go out of scope
   h->ham.n_groups = (int)gx.size();
   h->ham.n_terms = (int)term_z.size();
@@ -363,6 +564,9 @@ int build_hamiltonian(vqe_t* h) {
   h->ham.n_real = n_real;
   h->ham.n_cls = n_cls;
   for (int i = 0; i < 16; ++i) h->ham.mrow[i] = im.row[i];
+  h->ham.n_units = (int)(urec.size() / 8);
+  h->ham.urec = h->d_urec.p;
+  h->ham.utab = h->d_utab.p;
   h->ham.term_off = h->d_term_off.p;
   h->ham.term_z = h->d_term_z.p;
   h->ham.term_cr = h->d_term_cr.p;
@@ -432,7 +636,11 @@ int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
 int dispatch_lds(vqe_t* h, int which, const BatchArgs& A) {
   switch (h->n) {
 #define C(N) case N: return launch_lds<N>(h, which, A);
+#ifdef VQE_ONLY_N      // kernel experiments (tools/build_only_n.sh): one size, seconds to build
+    C(VQE_ONLY_N)
+#else
     C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13)
+#endif
 #undef C
   }
   return fail(h, VQE_EINVAL, "n_qubits outside the LDS-resident range");
@@ -887,6 +1095,13 @@ int vqe_hamiltonian_terms(vqe_t* h, int32_t* n_terms, int32_t* n_xgroups) {
   if (!h->ham_set) return fail(h, VQE_ESTATE, "no Hamiltonian set");
   *n_terms = (int32_t)h->hx.size();
   *n_xgroups = (int32_t)h->gx_all.size();
+  return VQE_OK;
+}
+
+int vqe_hamiltonian_layout(vqe_t* h, int32_t out[4]) {
+  if (!h || !out) return VQE_EINVAL;
+  if (!h->ham_set) return fail(h, VQE_ESTATE, "no Hamiltonian set");
+  out[0] = h->ham.n_groups; out[1] = h->ham.n_units; out[2] = h->ham.n_cls; out[3] = h->ham.has_diag;
   return VQE_OK;
 }
 

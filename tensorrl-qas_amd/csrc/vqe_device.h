@@ -115,6 +115,16 @@ struct HamDev {
   // of the R register bits LT..n-1 of p'); masks and tables below are expressed in p'.
   int n_cls;                // leading real groups whose x' has a register bit (multiple of energy_pd(n))
   uint32_t mrow[16];        // row i of M: bit i of p' = parity(mrow[i] & p)
+  // unit path (LDS-resident kernels): X-mask groups whose sign-sum table is mostly EXACT zeros (fermionic excitation
+  // operators connect one occupation pattern in 2^w) are stored as *units* - sub-cubes of NT pairs on which the table
+  // does not vanish - and never enter the group lists above.  A unit fixes F = n-1-LT bit positions (plus the
+  // selector bit that tells the two members of a pair apart); thread t owns the pair whose remaining LT index bits
+  // are the bits of t.  urec: 8 words per unit {m0..m4: byte-address masks of the bit deposit, s16: the fixed bits,
+  // x16: the X mask, toff: byte offset of its NT table doubles in utab}; n_units is a multiple of kUnitUnroll
+  // (zero-table padding).
+  int n_units;
+  const uint32_t* urec;
+  const double* utab;
   // streaming path (n >= 14): explicit terms
   int n_terms;              // terms of the groups above
   const int32_t* term_off;  // [n_groups + 1]
@@ -122,6 +132,9 @@ struct HamDev {
   const double* term_cr;    // [n_terms] real part of c_k (incl. i^{#Y})
   const double* term_ci;    // [n_terms]
 };
+
+constexpr int kUnitTrip = 4;                  // units per trip of the unit loop
+constexpr int kUnitUnroll = 3 * kUnitTrip;    // HamDev::n_units is padded to a multiple of this (three trips per turn of the loop)
 
 struct NoiseCfg { double p1, p2; uint64_t seed; uint64_t eval_base; double shot_sigma; };
 
@@ -1084,6 +1097,86 @@ __device__ __forceinline__ void pair_fma1(double& acc0, const double2& a0, const
       : "+v"(acc0), "=&v"(t0) : "v"(a0.x), "v"(a0.y), "v"(b[0].x), "v"(b[0].y), "v"(d0));
 }
 
+// Unit path: the X-mask groups whose sign-sum tables are mostly exact zeros (HamDev::urec, built by the host).  One
+// pair per thread and unit, both members from LDS: the record (8 scalars, read with scalar loads - the records sit
+// in the constant address space) gives the byte-address masks that deposit the thread id into the free index bits,
+// the fixed bits, the X mask and the offset of the unit's NT table values.  No dispatch of any kind: 7 integer
+// instructions, 2 ds_read_b128, one 8-byte table load and 3 FP64 instructions per unit and thread, against ~60
+// instructions, 8 ds_read_b128 and 64 table bytes for a group of the class path below.
+typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(4))) const u32x8_t const_u32x8;
+
+template <int N>
+__device__ __forceinline__ void unit_energy(const Lds& L, const HamDev& H, double& acc0, double& acc1) {
+  constexpr int LT = Geo<N>::LT;
+  constexpr int SEG = (N - 1 - LT) + 2;      // holes (fixed bits + selector) + 1 runs of free positions
+  static_assert(SEG >= 2 && SEG <= 5, "unit records hold five deposit masks");
+  constexpr int U = kUnitTrip;
+  static_assert(kUnitUnroll == 3 * kUnitTrip, "three trips per turn of the loop (ring of three table buffers)");
+  constexpr uint32_t TSTRIDE = (uint32_t)8 << LT;   // table bytes of one unit (units are stored in order)
+  const int nu = __builtin_amdgcn_readfirstlane(H.n_units);
+  if (nu <= 0) return;
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  lds_cbyte* psi_l = (lds_cbyte*)L.psi;
+  const __amdgpu_buffer_rsrc_t ru = table_rsrc(H.utab);
+  const const_u32x8* rec = (const const_u32x8*)H.urec;
+  uint32_t tsh[SEG];
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) tsh[i] = tid << (4 + i);
+  const uint32_t tid8 = tid << 3;
+  // A trip = U units.  Table values come from L2 two trips ahead (ring of three register buffers, the loop body is
+  // three trips so that the buffer indices are static).  The records of the next trip are requested into the SAME
+  // scalar registers once the addresses of this trip are formed, and land while its LDS reads are in flight
+  // (scalar and LDS loads share one counter: requested earlier, a wait for a record would also wait for LDS reads).
+  double d[3][U];
+  u32x8_t R[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    d[0][j] = buf_load_d(ru, tid8, (uint32_t)j * TSTRIDE);
+    d[1][j] = buf_load_d(ru, tid8, (uint32_t)(U + j) * TSTRIDE);
+    R[j] = rec[j];
+  }
+  const int last = nu - U;       // first unit of the last trip
+  for (int u = 0; u < nu; u += 3 * U) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ub = u + k * U;
+      const int u1 = ub + U < last ? ub + U : last;             // (past the end: re-read the last trip)
+      const int u2 = ub + 2 * U < last ? ub + 2 * U : last;
+      double2 pa[U], pb[U];
+      uint32_t a[U], ax[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        uint32_t v = R[j][5];
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) v |= tsh[i] & R[j][i];
+        a[j] = v;
+        ax[j] = v ^ R[j][6];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        pb[j] = lds_load_d2(psi_l, a[j]);
+        pa[j] = lds_load_d2(psi_l, ax[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) d[(k + 2) % 3][j] = buf_load_d(ru, tid8, (uint32_t)(u2 + j) * TSTRIDE);
+      __builtin_amdgcn_sched_barrier(0);
+      const const_u32x8* rn = rec + u1;
+#pragma unroll
+      for (int j = 0; j < U; ++j) R[j] = rn[j];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const double v = (pa[j].x * pb[j].x + pa[j].y * pb[j].y) * d[k][j];
+        if (j & 1) acc1 += v; else acc0 += v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // Register path (n >= 10).  The state arrives in LDS in canonical order p' = tid | r << LT; each
 // thread keeps its 2^R amplitudes own[r] in registers.  For a group whose x' has register bit
 // `cls` (the highest one) the pairs {p', p' ^ x'} are covered exactly once by taking as one
@@ -1224,6 +1317,7 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H, Hook
 #undef VQE_R_BODY
   }
   after_pairs();
+  unit_energy<N>(L, H, acc0, acc1);
   const int g1 = g0 + H.n_real;
   energy_real_lds<N>(L, tables, gc, g1, acc0, acc1);
   energy_imag_lds<N>(L, tables, g1, H.n_groups, acc0);

@@ -129,6 +129,12 @@ class VQEEngine:
         self._chk(self._lib.vqe_hamiltonian_terms(self._h, C.byref(nt), C.byref(ng)))
         return nt.value, ng.value
 
+    def hamiltonian_layout(self):
+        """How the LDS-resident kernels hold the Hamiltonian: table groups, units (mostly-zero groups), class groups."""
+        out = (C.c_int32 * 4)()
+        self._chk(self._lib.vqe_hamiltonian_layout(self._h, out))
+        return {"table_groups": out[0], "units": out[1], "class_groups": out[2], "has_diag": bool(out[3])}
+
     def set_term_shard(self, rank: int, world: int):
         self._chk(self._lib.vqe_set_term_shard(self._h, int(rank), int(world)))
 

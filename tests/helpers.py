@@ -97,3 +97,51 @@ def reference_config(name, data_root):
     conf = json.loads(json.dumps(conf))
     conf["env"]["data_root"] = data_root
     return conf
+
+
+def fermionic_hamiltonian(n, n_hop, n_quad, rng, dressed=0):
+    """Number-conserving Pauli sum of Jordan-Wigner shape on n qubits (the structure of the molecular Hamiltonians
+    the reference ships, reference dmrg-to-qc/mol_data): identity + Z + ZZ terms, ``n_hop`` hopping pairs
+    {X Z..Z X, Y Z..Z Y} with equal weights, ``n_quad`` double-excitation octets with the signs of
+    a+_p a+_q a_r a_s + h.c., and ``dressed`` hopping pairs multiplied by a number operator (1 - Z_k) / 2.
+    Returns (xmask, zmask, coeff) with coeff the coefficient of the Pauli STRING (Y = Y)."""
+    terms = {}
+
+    def add(x, z, w):
+        terms[(x, z)] = terms.get((x, z), 0.0) + w
+
+    wt = lambda: float(rng.normal() * 10.0 ** (-rng.uniform(0, 2)))
+    add(0, 0, wt())
+    for q in range(n):
+        add(0, 1 << q, wt())
+    for a in range(n):
+        for b in range(a + 1, n):
+            if rng.random() < 0.5:
+                add(0, (1 << a) | (1 << b), 0.1 * wt())
+    pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]
+    hop = [pairs[i] for i in rng.choice(len(pairs), min(n_hop + dressed, len(pairs)), replace=False)]
+    for i, (a, b) in enumerate(hop):
+        zs = sum(1 << k for k in range(a + 1, b))
+        w = 0.1 * wt()
+        x = (1 << a) | (1 << b)
+        if i < n_hop:
+            add(x, zs, w), add(x, zs | x, w)
+        else:                       # (1 - Z_k) / 2 times the hopping pair, k outside [a, b]
+            ks = [k for k in range(n) if k < a or k > b]
+            if not ks:
+                continue
+            k = int(rng.choice(ks))
+            for zz, sg in ((zs, 0.5), (zs | (1 << k), -0.5)):
+                add(x, zz, sg * w), add(x, zz | x, sg * w)
+    quads = [(a, b, c, d) for a in range(n) for b in range(a + 1, n) for c in range(b + 1, n) for d in range(c + 1, n)]
+    if quads:
+        for i in rng.choice(len(quads), min(n_quad, len(quads)), replace=False):
+            a, b, c, d = quads[i]
+            zs = sum(1 << k for k in range(a + 1, b)) | sum(1 << k for k in range(c + 1, d))
+            x = (1 << a) | (1 << b) | (1 << c) | (1 << d)
+            w = 0.05 * wt()
+            for ys, sg in (((), 1), ((c, d), -1), ((b, d), 1), ((b, c), 1), ((a, d), 1), ((a, c), 1), ((a, b), -1), ((a, b, c, d), 1)):
+                add(x, zs | sum(1 << k for k in ys), sg * w)
+    keys = sorted(terms)
+    return (np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64),
+            np.array([terms[k] for k in keys], np.float64))

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import vqe_oracle as vo
-from helpers import (CASES, known_answers, load_case, oracle_init_state, random_gates,
+from helpers import (CASES, fermionic_hamiltonian, known_answers, load_case, oracle_init_state, random_gates,
                      random_hamiltonian, random_state)
 
 pytestmark = pytest.mark.gpu
@@ -58,6 +58,47 @@ def test_energy_random(tq, n, T, G, seed, real):
     for i in range(7):
         r = vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, ths[i]), *ham)
         assert abs(got[i] - r) < E_TOL
+
+
+@pytest.mark.parametrize("n,hop,quad,dressed,dense,seed", [(10, 12, 20, 3, 4, 0), (11, 14, 30, 4, 0, 1), (12, 20, 50, 6, 5, 2),
+                                                           (13, 20, 40, 6, 3, 3), (12, 25, 0, 0, 0, 4)])
+def test_unit_path_fermionic_hamiltonians(tq, n, hop, quad, dressed, dense, seed):
+    """Register path with the unit lists (vqe_hamiltonian_layout): X-mask groups of number-conserving operators
+    (hopping pairs, double-excitation octets, number-operator-dressed hoppings) are stored as the sub-cubes on which
+    their sign-sum tables do not vanish; `dense` random terms keep the full-table groups in the same launch.
+    Energies against the oracle's plain Pauli sum, also term-sharded (units follow their group's owner) and through
+    the fused minimiser."""
+    rng = np.random.default_rng(4200 + seed)
+    psi0 = random_state(n, rng)
+    xs, zs, cs = fermionic_hamiltonian(n, hop, quad, rng, dressed)
+    if dense:
+        dx, dz, dc = random_hamiltonian(n, dense, rng)
+        keep = ~np.isin(dx, xs)                 # (an X mask shared with a sparse group would make that group dense)
+        xs, zs, cs = np.concatenate([xs, dx[keep]]), np.concatenate([zs, dz[keep]]), np.concatenate([cs, dc[keep]])
+    ham = (xs, zs, cs)
+    eng = _engine(tq, n, psi0, ham)
+    lay = eng.hamiltonian_layout()
+    assert lay["units"] > 0 and lay["units"] % 12 == 0
+    n_groups = len(set(xs.tolist()))
+    assert lay["table_groups"] < n_groups           # the sparse groups left the table lists
+    kind, q0, q1, pidx, th = random_gates(n, 40, rng)
+    eng.set_circuit(tq.Circuit(kind, q0, q1, pidx, th.size))
+    ths = np.concatenate([th[None, :], th[None, :] + rng.normal(size=(5, th.size))])
+    got = eng.energy_batch(ths)
+    ref = np.array([vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, t), *ham) for t in ths])
+    assert np.abs(got - ref).max() < E_TOL, np.abs(got - ref).max()
+    # sharded over 3 ranks: the partial sums add up to the same energies
+    parts = np.zeros(len(ths))
+    units = 0
+    for r in range(3):
+        e2 = _engine(tq, n, psi0, ham)
+        e2.set_term_shard(r, 3)
+        units += e2.hamiltonian_layout()["units"]
+        e2.set_circuit(tq.Circuit(kind, q0, q1, pidx, th.size))
+        parts += e2.energy_batch(ths)
+    assert np.abs(parts - ref).max() < E_TOL and units >= lay["units"]
+    x, f, nfev = eng.minimize_cobyla(th, 1.0, 1e-4, 60)
+    assert abs(f - vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, x), *ham)) < E_TOL and f <= ref[0] + 1e-12
 
 
 @pytest.mark.parametrize("case", CASES)
