@@ -107,6 +107,14 @@ int vqe_term_owner(int n_qubits, int n_terms, const uint64_t* xmask, int world, 
  * semantics: each non-identity Pauli with probability p/3 resp. p/15, one trajectory per
  * evaluation).  The draw for (stream, evaluation, gate) is a pure function of `seed`. */
 int vqe_set_noise(vqe_t* h, double p1, double p2, uint64_t seed);
+/* How the noise gates of a circuit are evaluated.  0 (default): one Pauli trajectory per evaluation, as qulacs does
+ * inside update_quantum_state (VQE_qulacs_TN_notin_RL_noise.py:94-101).  1: the exact channel those draws sample
+ * from - density-matrix evolution rho -> (1-p) rho + p/3 sum_P P rho P (two qubits: p/15 over the 15 non-identity
+ * Paulis), E = tr(rho H); 2 <= n <= 13 (4^n complex128 in HBM), runs of gates inside a two-qubit window fused into
+ * 16 x 16 superoperators applied with FP64 MFMA; vqe_energy*, vqe_batch_run_energy, vqe_minimize_cobyla,
+ * vqe_batch_run_minimize / _env_step (COBYLA then driven by the host on the exact energies).  The seed of
+ * vqe_set_noise and vqe_set_shot_noise play no part in mode 1. */
+int vqe_set_noise_mode(vqe_t* h, int mode);
 /* Finite-shot model of the reference's restricted variant
  * (environments/VQAs/VQE_qulacs_TN_notin_RL_noise_restricted.py:47-48,84-96): every evaluation
  * returns E + weights . N(0, sigma^2 I), sigma = n_shots^-1/2, i.e. E + sigma_total * N(0,1)

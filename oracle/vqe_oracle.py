@@ -101,6 +101,61 @@ def run_circuit(psi0, kinds, q0, q1, pidx, theta, noise_draws=None) -> np.ndarra
 
 
 # --------------------------------------------------------------------------------------
+# the channel the reference's noisy circuits sample from (density matrix)
+# --------------------------------------------------------------------------------------
+def run_circuit_dm(psi0, kinds, q0, q1, pidx, theta, p1, p2) -> np.ndarray:
+    """rho <- E_G(... E_1(|psi0><psi0|)): the unitary gates of ``run_circuit`` as rho -> U rho U^+ and the noise gates
+    as the CHANNELS qulacs' probabilistic gates sample one Kraus branch of per call
+    (VQE_qulacs_TN_notin_RL_noise.py:26-28,40-50,94-101; published qulacs semantics):
+    DepolarizingNoise(q, p): rho -> (1-p) rho + p/3 (X rho X + Y rho Y + Z rho Z);
+    TwoQubitDepolarizingNoise(a, b, p): rho -> (1-p) rho + p/15 sum over the 15 non-identity Paulis on (a, b).
+    rho is kept as a vector over 2n 'qubits' (bits 0..n-1: bra index, bits n..2n-1: ket index), so every step is an
+    ``apply_1q`` / ``apply_cnot`` of this file on the ket bit and its conjugate on the bra bit.  Returns rho[ket, bra]."""
+    psi0 = np.asarray(psi0, np.complex128)
+    n = int(round(math.log2(psi0.size)))
+    v = np.outer(psi0, np.conj(psi0)).reshape(-1)          # flat = ket * 2^n + bra: bra = low n bits
+
+    def both(vec, q, m):
+        return apply_1q(apply_1q(vec, n + q, m), q, np.conj(m))
+
+    for g in range(len(kinds)):
+        k = int(kinds[g])
+        if k == CNOT:
+            v = apply_cnot(apply_cnot(v, n + int(q0[g]), n + int(q1[g])), int(q0[g]), int(q1[g]))
+        elif k in (RX, RY, RZ):
+            v = both(v, int(q0[g]), rot_matrix(k, float(theta[pidx[g]])))
+        elif k == DEPOL1:
+            a = int(q0[g])
+            v = (1.0 - p1) * v + (p1 / 3.0) * sum(both(v, a, _PAULI_1Q[p]) for p in (1, 2, 3))
+        elif k == DEPOL2:
+            a, b = int(q0[g]), int(q1[g])
+            acc = np.zeros_like(v)
+            for pa in range(4):
+                for pb in range(4):
+                    if pa == 0 and pb == 0:
+                        continue
+                    w = v if pa == 0 else both(v, a, _PAULI_1Q[pa])
+                    acc += w if pb == 0 else both(w, b, _PAULI_1Q[pb])
+            v = (1.0 - p2) * v + (p2 / 15.0) * acc
+        else:
+            raise ValueError(k)
+    return v.reshape(2 ** n, 2 ** n)
+
+
+def energy_dm(rho: np.ndarray, xmask, zmask, coeff) -> float:
+    """tr(rho H) = sum_k w_k sum_i rho[i, i ^ x_k] i^{#Y} (-1)^{popc(i & z_k)}  (<j|P|i> is non-zero at j = i ^ x)."""
+    dim = rho.shape[0]
+    idx = np.arange(dim, dtype=np.int64)
+    e = 0.0
+    for x, z, w in zip(xmask, zmask, coeff):
+        x, z = int(x), int(z)
+        ny = bin(x & z).count("1")
+        val = np.sum(rho[idx, idx ^ x] * (1.0 - 2.0 * _parity(idx & z))) * (1j ** ny)
+        e += float(np.real(w)) * float(val.real) - float(np.imag(w)) * float(val.imag)
+    return float(e)
+
+
+# --------------------------------------------------------------------------------------
 # <psi|H|psi>
 # --------------------------------------------------------------------------------------
 def energy_dense(psi: np.ndarray, op: np.ndarray) -> float:

@@ -3,9 +3,11 @@
 #include "../../include/vqe_hip.h"
 #include "vqe_device.h"
 #include "vqe_stream.h"
+#include "vqe_dm.h"
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,6 +97,14 @@ struct vqe_handle {
   DevBuf<double> d_trace;
   bool trace_on = false;
   int trace_maxfun = 0, trace_stride = 0, trace_batch = 0;
+  // exact channel mode of the noisy path (vqe_set_noise_mode, vqe_dm.h): density matrix and its Hamiltonian terms
+  int noise_mode = 0;
+  DevBuf<double2> dm_rho;
+  DevBuf<double> dm_S, dm_partial, dm_cr, dm_ci;
+  DevBuf<uint32_t> dm_gx, dm_tz;
+  DevBuf<int32_t> dm_toff;
+  int dm_groups = 0;
+  uint64_t dm_ham_gen = ~0ull;
   StreamWork sw;  // streaming-path work buffers
   uint64_t gen = 0;   // bumped whenever a resident batch / Hamiltonian shard / noise setting changes (plans of vqe_tile.h)
 };
@@ -893,6 +903,257 @@ int stream_run(vqe_t* h, int which, BatchArgs& A) {
   return VQE_OK;
 }
 
+// ---- exact channel mode (vqe_dm.h) -----------------------------------------------------------------
+typedef std::complex<double> cplx;
+struct Sup { cplx m[16][16]; };      // superoperator on the window: entry index e = i + 4 j, i = ket bits (a, b), j = bra bits
+
+void sup_identity(Sup& S) {
+  for (int r = 0; r < 16; ++r) for (int c = 0; c < 16; ++c) S.m[r][c] = r == c ? 1.0 : 0.0;
+}
+// rho -> U rho U^+ :  S[(i, j), (i', j')] = U[i][i'] conj(U[j][j'])
+void sup_conj(const cplx U[4][4], Sup& S) {
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int ip = 0; ip < 4; ++ip) for (int jp = 0; jp < 4; ++jp)
+    S.m[i + 4 * j][ip + 4 * jp] = U[i][ip] * std::conj(U[j][jp]);
+}
+void sup_apply(Sup& acc, const Sup& G) {      // acc <- G acc
+  Sup t;
+  for (int r = 0; r < 16; ++r) for (int c = 0; c < 16; ++c) {
+    cplx v = 0.0;
+    for (int k = 0; k < 16; ++k) v += G.m[r][k] * acc.m[k][c];
+    t.m[r][c] = v;
+  }
+  acc = t;
+}
+// one-qubit operator on window position pos (0: qubit a = bit 0 of the 2-bit index, 1: qubit b)
+void embed_1q(const cplx R[2][2], int pos, cplx U[4][4]) {
+  for (int i = 0; i < 4; ++i) for (int ip = 0; ip < 4; ++ip) {
+    const int other = pos ^ 1;
+    U[i][ip] = (((i >> other) & 1) == ((ip >> other) & 1)) ? R[(i >> pos) & 1][(ip >> pos) & 1] : cplx(0.0);
+  }
+}
+void pauli_1q(int p, cplx R[2][2]) {          // 0 I, 1 X, 2 Y, 3 Z
+  R[0][0] = R[0][1] = R[1][0] = R[1][1] = 0.0;
+  if (p == 0) { R[0][0] = R[1][1] = 1.0; }
+  else if (p == 1) { R[0][1] = R[1][0] = 1.0; }
+  else if (p == 2) { R[0][1] = cplx(0.0, -1.0); R[1][0] = cplx(0.0, 1.0); }
+  else { R[0][0] = 1.0; R[1][1] = -1.0; }
+}
+// (1 - p) id + p / (4^k - 1) sum over the non-identity Paulis on the qubits of `mask` (bit 0: a, bit 1: b)
+void sup_depol(int mask, double p, Sup& S) {
+  const int k = (mask & 1) + ((mask >> 1) & 1);
+  const double w = p / (k == 2 ? 15.0 : 3.0);
+  for (int r = 0; r < 16; ++r) for (int c = 0; c < 16; ++c) S.m[r][c] = r == c ? 1.0 - p : 0.0;
+  for (int pa = 0; pa < 4; ++pa) for (int pb = 0; pb < 4; ++pb) {
+    if ((pa && !(mask & 1)) || (pb && !(mask & 2)) || (!pa && !pb)) continue;
+    cplx Ra[2][2], Rb[2][2], Ua[4][4], Ub[4][4], U[4][4];
+    pauli_1q(pa, Ra); pauli_1q(pb, Rb);
+    embed_1q(Ra, 0, Ua); embed_1q(Rb, 1, Ub);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+      cplx v = 0.0;
+      for (int m = 0; m < 4; ++m) v += Ua[i][m] * Ub[m][j];
+      U[i][j] = v;
+    }
+    Sup P;
+    sup_conj(U, P);
+    for (int r = 0; r < 16; ++r) for (int c = 0; c < 16; ++c) S.m[r][c] += w * P.m[r][c];
+  }
+}
+
+struct DmBlockHost { int a, b; Sup S; };
+
+// Gate list -> superoperator blocks: a block collects every consecutive gate / channel that stays inside its
+// two-qubit window.  Gate semantics as in vqe_device.h (qulacs: R = exp(+i theta/2 P), CNOT(control, target)).
+void dm_make_blocks(int n, const GateRec* g, int G, const double* theta, double p1, double p2, std::vector<DmBlockHost>& out) {
+  out.clear();
+  int wa = -1, wb = -1;
+  DmBlockHost cur{};
+  auto flush = [&]() { if (wa >= 0) out.push_back(cur); wa = wb = -1; };
+  for (int i = 0; i < G; ++i) {
+    const GateRec r = g[i];
+    const bool two = r.kind == G_CNOT || r.kind == G_DEPOL2;
+    const int qa = r.q0, qb = two ? r.q1 : -1;
+    const bool fits = wa >= 0 && (qa == wa || qa == wb) && (!two || qb == wa || qb == wb);
+    if (!fits) {
+      flush();
+      wa = qa;
+      wb = qb;
+      if (wb < 0) {      // a one-qubit gate opens the window: its partner is the other qubit of the next gate that touches it
+        for (int k = i + 1; k < G && wb < 0; ++k) {
+          const bool t2 = g[k].kind == G_CNOT || g[k].kind == G_DEPOL2;
+          if (t2 && g[k].q0 == qa) wb = g[k].q1;
+          else if (t2 && g[k].q1 == qa) wb = g[k].q0;
+          else if (t2) break;
+        }
+        if (wb < 0) wb = (qa + 1) % n;
+      }
+      cur.a = wa; cur.b = wb;
+      sup_identity(cur.S);
+    }
+    Sup Gs;
+    if (r.kind == G_CNOT) {
+      const int pc = r.q0 == wa ? 0 : 1, pt = pc ^ 1;
+      cplx U[4][4];
+      for (int x = 0; x < 4; ++x) for (int y = 0; y < 4; ++y) U[x][y] = (x == (y ^ (((y >> pc) & 1) << pt))) ? 1.0 : 0.0;
+      sup_conj(U, Gs);
+    } else if (r.kind >= G_RX && r.kind <= G_RZ) {
+      const double c = std::cos(0.5 * theta[r.pidx]), sn = std::sin(0.5 * theta[r.pidx]);
+      cplx R[2][2], U[4][4];
+      if (r.kind == G_RX) { R[0][0] = R[1][1] = c; R[0][1] = R[1][0] = cplx(0.0, sn); }
+      else if (r.kind == G_RY) { R[0][0] = R[1][1] = c; R[0][1] = sn; R[1][0] = -sn; }
+      else { R[0][0] = cplx(c, sn); R[1][1] = cplx(c, -sn); R[0][1] = R[1][0] = 0.0; }
+      embed_1q(R, r.q0 == wa ? 0 : 1, U);
+      sup_conj(U, Gs);
+    } else if (r.kind == G_DEPOL1) {
+      sup_depol(r.q0 == wa ? 1 : 2, p1, Gs);
+    } else {
+      sup_depol(3, p2, Gs);
+    }
+    sup_apply(cur.S, Gs);
+  }
+  flush();
+}
+
+// this handle's Hamiltonian terms (all of its share under term sharding) for k_dm_energy
+int dm_prepare_ham(vqe_t* h) {
+  if (h->dm_ham_gen == h->gen) return VQE_OK;
+  const std::vector<int> owner = assign_groups(h->gx_all, h->group_terms, h->lds_path, h->shard_world);
+  std::vector<uint32_t> gx, tz;
+  std::vector<int32_t> toff{0};
+  std::vector<double> cr, ci;
+  for (size_t g = 0; g < owner.size(); ++g) {
+    if (owner[g] != h->shard_rank) continue;
+    gx.push_back(h->gx_all[g]);
+    for (int k : h->group_terms[g]) { tz.push_back((uint32_t)h->hz[k]); cr.push_back(h->hcr[k]); ci.push_back(h->hci[k]); }
+    toff.push_back((int32_t)tz.size());
+  }
+  int rc;
+  if ((rc = upload(h, h->dm_gx, gx.data(), gx.size()))) return rc;
+  if ((rc = upload(h, h->dm_tz, tz.data(), tz.size()))) return rc;
+  if ((rc = upload(h, h->dm_toff, toff.data(), toff.size()))) return rc;
+  if ((rc = upload(h, h->dm_cr, cr.data(), cr.size()))) return rc;
+  if ((rc = upload(h, h->dm_ci, ci.data(), ci.size()))) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->dm_groups = (int)gx.size();
+  h->dm_ham_gen = h->gen;
+  return VQE_OK;
+}
+
+// tr(rho H) of one circuit into *e_host (blocking)
+int dm_energy_one(vqe_t* h, const GateRec* g, int G, const double* theta, double* e_host) {
+  const int n = h->n;
+  std::vector<DmBlockHost> blocks;
+  dm_make_blocks(n, g, G, theta, h->noise.p1, h->noise.p2, blocks);
+  std::vector<double> S(blocks.size() * 512);
+  for (size_t k = 0; k < blocks.size(); ++k)
+    for (int r = 0; r < 16; ++r) for (int c = 0; c < 16; ++c) {
+      S[k * 512 + r * 16 + c] = blocks[k].S.m[r][c].real();
+      S[k * 512 + 256 + r * 16 + c] = blocks[k].S.m[r][c].imag();
+    }
+  const size_t total = (size_t)1 << (2 * n);
+  const int eb = (int)((((size_t)1 << n) + 255) / 256);
+  HIP_TRY(h, h->dm_rho.reserve(total));
+  HIP_TRY(h, h->dm_partial.reserve((size_t)eb + 1));
+  int rc;
+  if ((rc = upload(h, h->dm_S, S.data(), S.size()))) return rc;
+  const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, (size_t)h->cu_count * 16);
+  hipLaunchKernelGGL(k_dm_init, dim3(grid), dim3(256), 0, h->stream, h->dm_rho.p, (const double2*)h->init.p, n);
+  for (size_t k = 0; k < blocks.size(); ++k) {
+    DmBlockArgs A{};
+    A.rho = h->dm_rho.p; A.S = h->dm_S.p + k * 512; A.n = n; A.a = blocks[k].a; A.b = blocks[k].b;
+    int hb[4] = {A.a, A.b, A.a + n, A.b + n};
+    std::sort(hb, hb + 4);
+    for (int i = 0; i < 4; ++i) A.hole[i] = hb[i];
+    A.n_groups = (uint32_t)(total / 16);
+    const size_t tiles = (A.n_groups + 15) / 16;
+    const unsigned gb = (unsigned)std::max<size_t>(1, std::min<size_t>((tiles + 3) / 4, (size_t)h->cu_count * 8));
+    hipLaunchKernelGGL(k_dm_block, dim3(gb), dim3(256), 0, h->stream, A);
+  }
+  hipLaunchKernelGGL(k_dm_energy, dim3(eb), dim3(256), 0, h->stream, (const double2*)h->dm_rho.p, n, h->dm_groups,
+                     (const uint32_t*)h->dm_gx.p, (const int32_t*)h->dm_toff.p, (const uint32_t*)h->dm_tz.p,
+                     (const double*)h->dm_cr.p, (const double*)h->dm_ci.p, h->dm_partial.p);
+  hipLaunchKernelGGL(k_dm_sum, dim3(1), dim3(64), 0, h->stream, (const double*)h->dm_partial.p, eb, h->dm_partial.p + eb);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(e_host, h->dm_partial.p + eb, 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));      // (S and the blocks go out of scope)
+  return VQE_OK;
+}
+
+// The resident batch in exact channel mode: which = 0 energies, 1 COBYLA (host-driven on exact energies; with
+// A.env_step the pre-action circuit, float32 round trip and the energy of the full circuit, as the fused kernel does).
+int dm_run(vqe_t* h, int which, const BatchArgs& A) {
+  if (h->n < 2 || h->n > 13) return fail(h, VQE_EINVAL, "the exact channel mode (density matrix) serves 2 <= n_qubits <= 13");
+  if (h->amp_world > 1) return fail(h, VQE_ESTATE, "the exact channel mode has no amplitude sharding");
+  int rc = dm_prepare_ham(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  const int B = h->batch;
+  std::vector<double> f(B, 0.0), x(h->h_theta), xraw(h->h_theta);
+  std::vector<int32_t> nfev(B, 1);
+  for (int b = 0; b < B; ++b) {
+    const GateRec* g = h->h_gates.data() + h->h_gate_begin[b];
+    const int G = h->h_gate_count[b], P = h->h_par_count[b];
+    double* xb = x.data() + h->h_par_begin[b];
+    if (which == 0) {
+      if ((rc = dm_energy_one(h, g, G, xb, &f[b]))) return rc;
+      continue;
+    }
+    // the circuit COBYLA sees: without the new gate (and the channel attached to it) when this is an env-step
+    const int skip = (A.env_step && h->has_new_gate) ? h->h_new_gate[b] : -1;
+    int skip_end = skip + 1, hole = -1;
+    if (skip >= 0) {
+      const GateRec r = g[skip];
+      if (r.kind >= G_RX && r.kind <= G_RZ) hole = r.pidx;
+      if (skip + 1 < G) {
+        const GateRec fo = g[skip + 1];
+        if ((fo.kind == G_DEPOL1 && r.kind >= G_RX && r.kind <= G_RZ && fo.q0 == r.q0) ||
+            (fo.kind == G_DEPOL2 && r.kind == G_CNOT && fo.q0 == r.q0 && fo.q1 == r.q1))
+          skip_end = skip + 2;
+      }
+    }
+    std::vector<GateRec> g2;
+    for (int i = 0; i < G; ++i) {
+      if (i >= skip && i < skip_end) continue;
+      GateRec r = g[i];
+      if (r.kind >= G_RX && r.kind <= G_RZ && hole >= 0 && r.pidx > hole) r.pidx -= 1;
+      g2.push_back(r);
+    }
+    std::vector<double> xo;
+    for (int j = 0; j < P; ++j) if (j != hole) xo.push_back(xb[j]);
+    double fo = 0.0;
+    if (xo.empty()) {      // scipy returns after one evaluation
+      if ((rc = dm_energy_one(h, g2.data(), (int)g2.size(), xo.data(), &fo))) return rc;
+    } else {
+      vqe_cobyla_t* cob = nullptr;
+      if (vqe_cobyla_create((int)xo.size(), xo.data(), A.rhobeg, A.rhoend, A.maxfun, &cob)) return fail(h, VQE_ENOMEM, "host COBYLA allocation failed");
+      std::vector<double> xt(xo.size());
+      while (vqe_cobyla_ask(cob, xt.data()) == 1) {
+        double e;
+        if ((rc = dm_energy_one(h, g2.data(), (int)g2.size(), xt.data(), &e))) { vqe_cobyla_destroy(cob); return rc; }
+        vqe_cobyla_tell(cob, e);
+      }
+      vqe_cobyla_result(cob, xo.data(), &fo, &nfev[b], nullptr);
+      vqe_cobyla_destroy(cob);
+    }
+    double* xr = xraw.data() + h->h_par_begin[b];
+    for (int j = 0, k = 0; j < P; ++j) {
+      const double v = j == hole ? xb[j] : xo[k++];
+      xr[j] = v;
+      xb[j] = A.env_step ? (double)(float)v : v;
+    }
+    f[b] = fo;
+    if (A.env_step && (rc = dm_energy_one(h, g, G, xb, &f[b]))) return rc;
+  }
+  if (which != 0 && h->total_params) {
+    HIP_TRY(h, hipMemcpyAsync(h->d_x.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_xraw.p, xraw.data(), xraw.size() * 8, hipMemcpyHostToDevice, h->stream));
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->d_f.p, f.data(), (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_nfev.p, nfev.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VQE_OK;
+}
+
 int run(vqe_t* h, int which, double rhobeg, double rhoend, int maxfun) {
   HIP_TRY(h, hipSetDevice(h->dev));
   BatchArgs A = make_args(h);
@@ -916,6 +1177,7 @@ int run(vqe_t* h, int which, double rhobeg, double rhoend, int maxfun) {
     A.trace = h->d_trace.p;
     h->trace_maxfun = maxfun; h->trace_stride = (int)stride; h->trace_batch = h->batch;
   }
+  if (h->noise_mode == 1 && (which == 0 || which == 1 || which == 3)) return dm_run(h, which == 0 ? 0 : 1, A);
   if (h->lds_path) rc = dispatch_lds(h, which, A);
   else rc = stream_run(h, which, A);
   if (rc) return rc;
@@ -1132,6 +1394,14 @@ int vqe_set_noise(vqe_t* h, double p1, double p2, uint64_t seed) {
   if (!(p1 >= 0.0 && p1 <= 1.0 && p2 >= 0.0 && p2 <= 1.0)) return fail(h, VQE_EINVAL, "noise probability outside [0,1]");
   h->noise = NoiseCfg{p1, p2, seed, 0ull, h->noise.shot_sigma};
   ++h->gen;
+  return VQE_OK;
+}
+
+int vqe_set_noise_mode(vqe_t* h, int mode) {
+  if (!h) return VQE_EINVAL;
+  if (mode != 0 && mode != 1) return fail(h, VQE_EINVAL, "noise mode: 0 (Pauli trajectories) or 1 (exact channel)");
+  if (mode == 1 && (h->n < 2 || h->n > 13)) return fail(h, VQE_EINVAL, "the exact channel mode (density matrix) serves 2 <= n_qubits <= 13");
+  h->noise_mode = mode;
   return VQE_OK;
 }
 

@@ -144,6 +144,10 @@ class VQEEngine:
     def set_noise(self, p1: float, p2: float, seed: int):
         self._chk(self._lib.vqe_set_noise(self._h, float(p1), float(p2), C.c_uint64(int(seed) & (2 ** 64 - 1))))
 
+    def set_noise_mode(self, mode: int):
+        """0: Pauli trajectories (one draw per evaluation); 1: the exact channel (density matrix, n <= 13)."""
+        self._chk(self._lib.vqe_set_noise_mode(self._h, int(mode)))
+
     def set_shot_noise(self, sigma_total: float, seed: int):
         self._chk(self._lib.vqe_set_shot_noise(self._h, float(sigma_total), C.c_uint64(int(seed) & (2 ** 64 - 1))))
 

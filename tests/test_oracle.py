@@ -119,3 +119,38 @@ def test_state_tensor_ordering():
     assert k.tolist() == [0, 0, 1, 3, 2]
     assert a.tolist() == [3, 0, 3, 0, 2] and b.tolist() == [1, 2, -1, -1, -1]
     assert p.tolist() == [-1, -1, 0, 1, 2] and th.tolist() == [-0.25, 0.5, 1.5]
+
+
+def test_channel_restatement_equals_the_weighted_sum_over_all_trajectories():
+    """run_circuit_dm / energy_dm (the channel of the reference's noise gates) against the definition: the sum over
+    EVERY Pauli trajectory of run_circuit, weighted with its probability (two channels: 4 x 16 branches)."""
+    import itertools
+    from helpers import random_gates, random_hamiltonian, random_state
+    rng = np.random.default_rng(0)
+    n = 4
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 20, rng, real=False)
+    k, a, b, p, th = random_gates(n, 6, rng)
+    k[0], b[0] = 0, (a[0] + 1) % n                      # at least one CNOT and one rotation
+    k[1], b[1], p[1] = 2, -1, 0
+    th = np.resize(th, max(1, int(p.max()) + 1))
+    kind, q0, q1, pidx = [], [], [], []
+    for kk, aa, bb, pp in zip(k, a, b, p):
+        kind.append(kk), q0.append(aa), q1.append(bb), pidx.append(pp)
+    kind[2:2] = [5]; q0[2:2] = [a[0]]; q1[2:2] = [b[0]]; pidx[2:2] = [-1]      # behind ... (position is irrelevant here)
+    kind.append(4), q0.append(a[1]), q1.append(-1), pidx.append(-1)
+    kind, q0, q1, pidx = (np.array(v) for v in (kind, q0, q1, pidx))
+    p1, p2 = 0.2, 0.3
+    rho = vo.run_circuit_dm(psi0, kind, q0, q1, pidx, th, p1, p2)
+    assert abs(np.trace(rho) - 1) < 1e-13 and np.abs(rho - rho.conj().T).max() < 1e-14
+    opts = [[(0, 1 - p1)] + [(d, p1 / 3) for d in (1, 2, 3)] if kk == 4 else
+            [(0, 1 - p2)] + [(d, p2 / 15) for d in range(1, 16)] if kk == 5 else [(0, 1.0)] for kk in kind]
+    tot = 0.0
+    for combo in itertools.product(*opts):
+        w = float(np.prod([c[1] for c in combo]))
+        tot += w * vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th, [c[0] for c in combo]), *ham)
+    assert abs(tot - vo.energy_dm(rho, *ham)) < 1e-12
+    # no noise: the channel is the unitary circuit
+    rho0 = vo.run_circuit_dm(psi0, kind, q0, q1, pidx, th, 0.0, 0.0)
+    psi = vo.run_circuit(psi0, kind, q0, q1, pidx, th)
+    assert np.abs(rho0 - np.outer(psi, psi.conj())).max() < 1e-14
