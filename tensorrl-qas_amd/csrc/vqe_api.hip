@@ -183,6 +183,26 @@ IndexMap identity_map(int n) {
   return m;
 }
 
+// M^-1 by Gauss-Jordan on [M | I] (rows as bit masks) -> inv_col
+void finish_inverse(IndexMap& m) {
+  const int n = m.n;
+  uint32_t a[32], inv[32];
+  for (int i = 0; i < n; ++i) { a[i] = m.row[i]; inv[i] = 1u << i; }
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    while (piv < n && !((a[piv] >> c) & 1u)) ++piv;
+    std::swap(a[c], a[piv]);
+    std::swap(inv[c], inv[piv]);
+    for (int r = 0; r < n; ++r)
+      if (r != c && ((a[r] >> c) & 1u)) { a[r] ^= a[c]; inv[r] ^= inv[c]; }
+  }
+  for (int i = 0; i < n; ++i) {
+    uint32_t col = 0;
+    for (int j = 0; j < n; ++j) col |= ((inv[j] >> i) & 1u) << j;
+    m.inv_col[i] = col;
+  }
+}
+
 IndexMap choose_index_map(int n, int lt, const std::vector<uint32_t>& xs) {
   IndexMap m;
   m.n = n;
@@ -221,22 +241,7 @@ IndexMap choose_index_map(int n, int lt, const std::vector<uint32_t>& xs) {
   int filled = 0;
   for (int bit = 0; bit < n && filled < lt; ++bit)
     if (independent(1u << bit)) { add_row(1u << bit); m.row[filled++] = 1u << bit; }
-  // M^-1 by Gauss-Jordan on [M | I] (rows as bit masks)
-  uint32_t a[32], inv[32];
-  for (int i = 0; i < n; ++i) { a[i] = m.row[i]; inv[i] = 1u << i; }
-  for (int c = 0; c < n; ++c) {
-    int piv = c;
-    while (piv < n && !((a[piv] >> c) & 1u)) ++piv;
-    std::swap(a[c], a[piv]);
-    std::swap(inv[c], inv[piv]);
-    for (int r = 0; r < n; ++r)
-      if (r != c && ((a[r] >> c) & 1u)) { a[r] ^= a[c]; inv[r] ^= inv[c]; }
-  }
-  for (int i = 0; i < n; ++i) {
-    uint32_t col = 0;
-    for (int j = 0; j < n; ++j) col |= ((inv[j] >> i) & 1u) << j;
-    m.inv_col[i] = col;
-  }
+  finish_inverse(m);
   return m;
 }
 
@@ -358,7 +363,7 @@ int build_hamiltonian(vqe_t* h) {
   // register path: canonical index p' = M p (see IndexMap); all masks below are in p'
   const bool reg_path = h->lds_path && n >= kRegMinQubits;
   const int lt = geo_lt(n);                        // Geo<N>::LT of the register path
-  IndexMap im = identity_map(n);
+  IndexMap im = identity_map(n), pm = identity_map(n);      // pm: the qubit permutation under the units' bank shear
   // unit path (register path only): pass 1 in the qubit order as given - which groups are sparse, which qubits are
   // their fixed / selector bits
   const int unit_F = n - 1 - lt;
@@ -394,7 +399,17 @@ int build_hamiltonian(vqe_t* h) {
         dense_xs.push_back(x);
       }
     }
-    if (any_sparse) im = choose_permutation(n, lt, dense_xs, hole_freq);
+    if (any_sparse) {
+      pm = choose_permutation(n, lt, dense_xs, hole_freq);
+      // the canonical map of the handle: the permutation followed by the bank shear of the unit path (kSwzCode)
+      im = pm;
+      if (kUnitShear) {
+        for (int i = 0; i < 4 && i < n; ++i)
+          for (int j = 4; j < 8 && j < n; ++j)
+            if ((kSwzCode[j - 4] >> i) & 1u) im.row[i] ^= pm.row[j];
+        finish_inverse(im);
+      }
+    }
   }
   if (reg_path && !any_sparse) {
     std::vector<uint32_t> xs;
@@ -411,10 +426,10 @@ int build_hamiltonian(vqe_t* h) {
     std::vector<int> fixed;
     for (int g : mine) {
       if (!sparse[g]) continue;
-      const uint32_t x = im.map_x(h->gx_all[g]);
+      const uint32_t x = pm.map_x(h->gx_all[g]);      // the cubes are axis aligned in the permuted index, before the shear
       const int sel = 31 - __builtin_clz(x);
       double scale;
-      pair_table(h, g, im, n, sel, D, &scale);
+      pair_table(h, g, pm, n, sel, D, &scale);
       auto rep = [&](size_t q) { return (uint32_t)(((q >> sel) << (sel + 1)) | (q & (((size_t)1 << sel) - 1))); };
       act.clear();
       for (size_t q = 0; q < D.size(); ++q) if (std::fabs(D[q]) > kUnitZeroTol * scale) act.push_back(rep(q));
@@ -445,7 +460,7 @@ int build_hamiltonian(vqe_t* h) {
       for (int ki = 0; ki < n_keys; ++ki) {
         const uint32_t s = seen_keys[ki];
         const uint32_t toff = (uint32_t)(utab.size() * sizeof(double));
-        const uint32_t rec[8] = {m[0], m[1], m[2], m[3], m[4], s << 4, x << 4, toff};
+        const uint32_t rec[8] = {m[0], m[1], m[2], m[3], m[4], (kUnitShear ? swz_index(s) : s) << 4, (kUnitShear ? swz_index(x) : x) << 4, toff};
         urec.insert(urec.end(), rec, rec + 8);
         for (size_t t = 0; t < NT; ++t) {
           uint32_t p0 = s, tb = 0;       // deposit the bits of t into the free positions, ascending
@@ -629,6 +644,11 @@ int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
                                         : (noisy ? (const void*)k_lds_minimize<N, kW, true> : (const void*)k_lds_minimize<N, kW, false>))
                                 : (const void*)k_lds_state<N>;
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  {   // the unit loop addresses the state region absolutely (lds_load_abs): the dynamic LDS must start at 0
+    hipFuncAttributes fa;
+    HIP_TRY(h, hipFuncGetAttributes(&fa, fn));
+    if (fa.sharedSizeBytes != 0) return fail(h, VQE_ESTATE, "LDS-resident kernel was built with static LDS");
+  }
   h->last_wg_per_cu = std::max(1, std::min(8, (int)(h->lds_per_cu / lds)));
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
   const dim3 grid(which == 2 ? 1 : A.batch), block(Geo<N>::NT);
