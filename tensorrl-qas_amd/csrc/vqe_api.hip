@@ -105,6 +105,8 @@ struct vqe_handle {
   DevBuf<int32_t> dm_toff;
   int dm_groups = 0;
   uint64_t dm_ham_gen = ~0ull;
+  DevBuf<double> d_cob_x0, d_cob_xres, d_cob_f;      // device-resident lock-step COBYLA of the streaming path
+  DevBuf<int32_t> d_cob_nfev, d_cob_active;
   StreamWork sw;  // streaming-path work buffers
   uint64_t gen = 0;   // bumped whenever a resident batch / Hamiltonian shard / noise setting changes (plans of vqe_tile.h)
 };
@@ -364,13 +366,13 @@ int build_hamiltonian(vqe_t* h) {
   const bool reg_path = h->lds_path && n >= kRegMinQubits;
   const int lt = geo_lt(n);                        // Geo<N>::LT of the register path
   IndexMap im = identity_map(n), pm = identity_map(n);      // pm: the qubit permutation under the units' bank shear
-  // unit path (register path only): pass 1 in the qubit order as given - which groups are sparse, which qubits are
+  // unit path (8 <= n <= 13): pass 1 in the qubit order as given - which groups are sparse, which qubits are
   // their fixed / selector bits
   const int unit_F = n - 1 - lt;
   static const bool units_on = [] { const char* e = std::getenv("VQE_UNITS"); return !(e && e[0] == '0'); }();   // A/B knob
   std::vector<char> sparse(h->gx_all.size(), 0);
   bool any_sparse = false;
-  if (reg_path && units_on && unit_F >= 1) {
+  if (h->lds_path && n >= kUnitMinQubits && units_on && unit_F >= 1) {
     std::vector<int> hole_freq(n, 0);
     std::vector<uint32_t> dense_xs;
     std::vector<double> D;
@@ -399,7 +401,7 @@ int build_hamiltonian(vqe_t* h) {
         dense_xs.push_back(x);
       }
     }
-    if (any_sparse) {
+    if (any_sparse && reg_path) {      // (below the register path the state stays in logical order)
       pm = choose_permutation(n, lt, dense_xs, hole_freq);
       // the canonical map of the handle: the permutation followed by the bank shear of the unit path (kSwzCode)
       im = pm;
@@ -786,11 +788,16 @@ int ready(vqe_t* h) {
   return VQE_OK;
 }
 
-// Host-driven COBYLA of all resident streams in lock-step (one batched evaluation per iteration): the
-// streaming path's form of scipy.optimize.minimize(..., method='COBYLA') (environment_qulacs_TN_notin_agent.py:478).
-// x: in x0, out the result (layout pbeg / pcnt); trial points travel through d_x.
-int stream_cobyla(vqe_t* h, BatchArgs& A, const std::vector<int64_t>& pbeg, const std::vector<int32_t>& pcnt,
-                  std::vector<double>& x, std::vector<double>& f, std::vector<int32_t>& nfev) {
+// COBYLA of all resident streams in lock-step (one batched evaluation per iteration): the streaming path's form of
+// scipy.optimize.minimize(..., method='COBYLA') (environment_qulacs_TN_notin_agent.py:478).  The optimiser state of
+// every stream lives on the device (k_s_cobyla: the host build's arithmetic, one thread per stream); the host only
+// queues launches and looks at the number of running streams every kStreamPoll iterations - no copy of trial points
+// or energies and no synchronisation per evaluation (VQE_STREAM_HOST_COBYLA=1: the round-2 host-driven loop, kept
+// for A/B runs).  x: in x0, out the result (layout pbeg / pcnt); trial points travel through d_x.
+constexpr int kStreamPoll = 8;
+
+int stream_cobyla_host(vqe_t* h, BatchArgs& A, const std::vector<int64_t>& pbeg, const std::vector<int32_t>& pcnt,
+                       std::vector<double>& x, std::vector<double>& f, std::vector<int32_t>& nfev) {
   const int B = h->batch;
   std::vector<vqe_cobyla_t*> cob(B, nullptr);
   struct Guard { std::vector<vqe_cobyla_t*>& v; ~Guard() { for (auto* c : v) vqe_cobyla_destroy(c); } } guard{cob};
@@ -818,8 +825,55 @@ int stream_cobyla(vqe_t* h, BatchArgs& A, const std::vector<int64_t>& pbeg, cons
   return VQE_OK;
 }
 
-// Streaming path (n >= 14): kernels per op; the COBYLA loop is host driven, all streams in
-// lock-step (one batched evaluation per iteration).
+// d_pbeg / d_pcnt: the device copies of pbeg / pcnt (the batch that A describes)
+int stream_cobyla(vqe_t* h, BatchArgs& A, const std::vector<int64_t>& pbeg, const std::vector<int32_t>& pcnt,
+                  std::vector<double>& x, std::vector<double>& f, std::vector<int32_t>& nfev,
+                  const int64_t* d_pbeg, const int32_t* d_pcnt) {
+  static const bool host_loop = [] { const char* e = std::getenv("VQE_STREAM_HOST_COBYLA"); return e && e[0] == '1'; }();
+  if (host_loop) return stream_cobyla_host(h, A, pbeg, pcnt, x, f, nfev);
+  const int B = h->batch;
+  const size_t PT = x.size();
+  HIP_TRY(h, h->d_x.reserve(PT + 1));
+  HIP_TRY(h, h->d_cob_x0.reserve(PT + 1));
+  HIP_TRY(h, h->d_cob_xres.reserve(PT + 1));
+  HIP_TRY(h, h->d_cob_f.reserve(B));
+  HIP_TRY(h, h->d_cob_nfev.reserve(B));
+  HIP_TRY(h, h->d_cob_active.reserve((size_t)B + 1));
+  if (PT) HIP_TRY(h, hipMemcpyAsync(h->d_cob_x0.p, x.data(), PT * 8, hipMemcpyHostToDevice, h->stream));
+  // (trial points of streams that finish early stay where they are: the evaluations go on in lock-step over all streams)
+  if (PT) HIP_TRY(h, hipMemcpyAsync(h->d_x.p, x.data(), PT * 8, hipMemcpyHostToDevice, h->stream));
+  int32_t* n_active = h->d_cob_active.p + B;
+  const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+  HIP_TRY(h, hipMemsetAsync(n_active, 0, 4, h->stream));
+  hipLaunchKernelGGL(k_s_cobyla<true>, grid, block, 0, h->stream, B, d_pbeg, d_pcnt, (const int64_t*)h->d_scratch_begin.p,
+                     h->d_scratch.p, (const double*)h->d_cob_x0.p, h->d_x.p, (const double*)h->d_f.p, A.rhobeg, A.rhoend,
+                     A.maxfun, h->d_cob_active.p, n_active, h->d_cob_xres.p, h->d_cob_f.p, h->d_cob_nfev.p);
+  A.theta = h->d_x.p;
+  uint64_t it = 0;
+  int32_t running = 1;
+  while (running > 0) {
+    int rc = stream_evaluate(h->sw, A, A.ham.n_terms, h->stream, h->noise.eval_base + (++it), true, h->err, true, h->gen);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemsetAsync(n_active, 0, 4, h->stream));
+    hipLaunchKernelGGL(k_s_cobyla<false>, grid, block, 0, h->stream, B, d_pbeg, d_pcnt, (const int64_t*)h->d_scratch_begin.p,
+                       h->d_scratch.p, (const double*)h->d_cob_x0.p, h->d_x.p, (const double*)h->d_f.p, A.rhobeg, A.rhoend,
+                       A.maxfun, h->d_cob_active.p, n_active, h->d_cob_xres.p, h->d_cob_f.p, h->d_cob_nfev.p);
+    if (it % kStreamPoll == 0 || it >= (uint64_t)A.maxfun) {
+      HIP_TRY(h, hipMemcpyAsync(&running, n_active, 4, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    if (it > (uint64_t)A.maxfun + kStreamPoll) return fail(h, VQE_ESTATE, "device COBYLA did not terminate");
+  }
+  HIP_TRY(h, hipGetLastError());
+  if (PT) HIP_TRY(h, hipMemcpyAsync(x.data(), h->d_cob_xres.p, PT * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(f.data(), h->d_cob_f.p, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(nfev.data(), h->d_cob_nfev.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VQE_OK;
+}
+
+// Streaming path (n >= 14): kernels per op; the COBYLA loop runs all streams in lock-step (one batched
+// evaluation per iteration), its state on the device (stream_cobyla).
 int stream_run(vqe_t* h, int which, BatchArgs& A) {
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
   int rc = 0;
@@ -840,7 +894,7 @@ int stream_run(vqe_t* h, int which, BatchArgs& A) {
     const int B = h->batch;
     std::vector<double> x(h->h_theta), f(B, 0.0);
     std::vector<int32_t> nfev(B);
-    rc = stream_cobyla(h, A, h->h_par_begin, h->h_par_count, x, f, nfev);
+    rc = stream_cobyla(h, A, h->h_par_begin, h->h_par_count, x, f, nfev, h->d_par_begin.p, h->d_par_count.p);
     if (rc) return rc;
     if (h->total_params)
       HIP_TRY(h, hipMemcpyAsync(h->d_x.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
@@ -898,7 +952,7 @@ int stream_run(vqe_t* h, int which, BatchArgs& A) {
     A2.par_begin = h->d_par_begin2.p; A2.par_count = h->d_par_count2.p;
     std::vector<double> f(B, 0.0);
     std::vector<int32_t> nfev(B);
-    rc = stream_cobyla(h, A2, pbeg2, pcnt2, x0, f, nfev);
+    rc = stream_cobyla(h, A2, pbeg2, pcnt2, x0, f, nfev, h->d_par_begin2.p, h->d_par_count2.p);
     if (rc) return rc;
     std::vector<double> xraw(h->h_theta), xr32(h->h_theta);
     for (int b = 0; b < B; ++b) {

@@ -150,6 +150,7 @@ __host__ __device__ constexpr uint32_t swz_index(uint32_t p) {      // permuted 
   return p ^ (((p >> 4) & 1u) * kSwzCode[0]) ^ (((p >> 5) & 1u) * kSwzCode[1]) ^ (((p >> 6) & 1u) * kSwzCode[2]) ^
          (((p >> 7) & 1u) * kSwzCode[3]);
 }
+constexpr int kUnitMinQubits = 8;             // below: a group has no more pairs than a workgroup has threads
 constexpr int kUnitTrip = 4;                  // units per trip of the unit loop
 constexpr int kUnitUnroll = 3 * kUnitTrip;    // HamDev::n_units is padded to a multiple of this (three trips per turn of the loop)
 
@@ -1029,6 +1030,9 @@ __device__ __forceinline__ void energy_imag_lds(const Lds& L, const double* __re
 }
 
 template <int N>
+__device__ __forceinline__ void unit_energy(const Lds& L, const HamDev& H, double& acc0, double& acc1);   // (below)
+
+template <int N>
 __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
   constexpr int kThreads = Geo<N>::NT;
   constexpr uint32_t DIM = 1u << N;
@@ -1053,6 +1057,7 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
   const int g1 = g0 + H.n_real;        // multiple of PD groups with real tables
   energy_real_lds<N>(L, tables, g0, g1, acc0, acc1);
   energy_imag_lds<N>(L, tables, g1, H.n_groups, acc0);
+  if constexpr (N >= kUnitMinQubits) unit_energy<N>(L, H, acc0, acc1);      // the mostly-zero groups (state in logical order here)
   return block_sum<Geo<N>::NW>(acc0 + acc1, L.red);
 }
 

@@ -526,4 +526,56 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
   return 0;
 }
 
+// ---- device-resident lock-step COBYLA of the streaming path ------------------------------------------------------
+// One THREAD per stream runs cobyla_m0.h in the host context (one thread, sums in index order, no FMA contraction): the
+// same bits as the library's host COBYLA, which is pinned against scipy's traces (tests/test_abi.py) - an evaluation of
+// a batch of streams takes milliseconds here, the optimiser's O(P^2) update is noise beside it, so nothing is gained
+// by spreading it over a wave and the trajectories stay those of the host build.  FIRST: start() from x0; else tell(f)
+// of the evaluation just made.  The trial point of every running stream goes to xtrial (the next evaluation's theta);
+// a stream that finishes writes its result (x, f, nfev as vqe_cobyla_result returns them) and clears its flag;
+// n_active counts the streams that want another evaluation.
+// Replaces the per-evaluation H2D / D2H / hipStreamSynchronize of the round-2 host loop (missing 3).
+template <bool FIRST>
+__global__ void __launch_bounds__(64) k_s_cobyla(int B, const int64_t* __restrict__ pbeg, const int32_t* __restrict__ pcnt,
+                                                 const int64_t* __restrict__ sbeg, double* __restrict__ scratch,
+                                                 const double* __restrict__ x0, double* __restrict__ xtrial,
+                                                 const double* __restrict__ f, double rhobeg, double rhoend, int maxfun,
+                                                 int32_t* __restrict__ active, int32_t* __restrict__ n_active,
+                                                 double* __restrict__ xres, double* __restrict__ fres,
+                                                 int32_t* __restrict__ nfres) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = pcnt[b];
+  const int64_t p0 = pbeg[b];
+  double* mem = scratch + sbeg[b];
+  cby::CobylaM0<cby::HostCtx, false> c;
+  c.bind(mem, n);
+  double* extra = mem + c.words();         // [0] the value told last
+  int want;
+  if (FIRST) {
+    for (int i = 0; i < n; ++i) c.x[i] = x0[p0 + i];
+    if (n == 0) { want = 1; c.nfvals = 1; c.status = cby::RUNNING; c.rho = rhobeg; c.rhoend = rhoend; c.maxfun = maxfun; c.ifull = 1;
+                  c.prerem = c.parsig = c.pareta = c.fbest_ret = 0.0; c.jdrop = c.ibrnch = c.iflag = 0; c.vcol = c.vrow = -2; }
+    else want = c.start(rhobeg, rhoend, maxfun);
+    extra[0] = 0.0;
+  } else {
+    if (!active[b]) return;
+    c.load_state();
+    const double fv = f[b];
+    extra[0] = fv;
+    if (n == 0) { want = 0; c.status = cby::DONE_RHOEND; c.ifull = 1; }
+    else want = c.tell(fv);
+  }
+  c.save_state();
+  active[b] = want;
+  if (want) {
+    for (int i = 0; i < n; ++i) xtrial[p0 + i] = c.x[i];
+    atomicAdd(n_active, 1);
+  } else {
+    for (int i = 0; i < n; ++i) xres[p0 + i] = c.x[i];
+    fres[b] = (c.status == cby::DONE_RHOEND && c.ifull == 1) ? extra[0] : c.fbest_ret;
+    nfres[b] = c.nfvals;
+  }
+}
+
 }  // namespace vqe

@@ -61,9 +61,10 @@ def test_energy_random(tq, n, T, G, seed, real):
 
 
 @pytest.mark.parametrize("n,hop,quad,dressed,dense,seed", [(10, 12, 20, 3, 4, 0), (11, 14, 30, 4, 0, 1), (12, 20, 50, 6, 5, 2),
-                                                           (13, 20, 40, 6, 3, 3), (12, 25, 0, 0, 0, 4)])
+                                                           (13, 20, 40, 6, 3, 3), (12, 25, 0, 0, 0, 4), (8, 10, 14, 2, 3, 5),
+                                                           (9, 12, 20, 3, 0, 6)])
 def test_unit_path_fermionic_hamiltonians(tq, n, hop, quad, dressed, dense, seed):
-    """Register path with the unit lists (vqe_hamiltonian_layout): X-mask groups of number-conserving operators
+    """LDS-resident kernels with the unit lists (vqe_hamiltonian_layout; 8 <= n <= 13): X-mask groups of number-conserving operators
     (hopping pairs, double-excitation octets, number-operator-dressed hoppings) are stored as the sub-cubes on which
     their sign-sum tables do not vanish; `dense` random terms keep the full-table groups in the same launch.
     Energies against the oracle's plain Pauli sum, also term-sharded (units follow their group's owner) and through
