@@ -71,6 +71,12 @@ int vqe_device_info(vqe_t* h, int64_t info[4]);
  * replaces: state.load(TN_state)            VQE_qulacs_TN_notin_RL.py:83
  *           (NULL = |0...0>, the VQE_qulacs.py:81 path) */
 int vqe_set_init_state(vqe_t* h, const double* amps_re_im /* 2 * 2^n, or NULL */);
+/* The same with the amplitudes in DEVICE memory (complex128, 2^n, e.g. a torch tensor): an asynchronous
+ * device-to-device copy on the handle's stream.  vqe_get_state_dev is vqe_get_state with a device destination.
+ * Used by the amplitude-sharded states (tensorrl-qas_amd/parallel.py), where a rank's shard of a larger register is
+ * the "state" of an (n - log2 world)-qubit handle and never leaves the GPU between two exchanges. */
+int vqe_set_init_state_dev(vqe_t* h, const void* dev_amps_re_im);
+int vqe_get_state_dev(vqe_t* h, const double* theta, void* dev_amps_re_im);
 /* replaces: the dense operator handed to get_exp_val (VQE_qulacs_TN_notin_RL.py:80,86;
  * built at environment_qulacs_TN_notin_agent.py:126-131,162) by its Pauli-sum form */
 int vqe_set_hamiltonian_pauli(vqe_t* h, int n_terms, const uint64_t* xmask,

@@ -1352,6 +1352,28 @@ int vqe_set_init_state(vqe_t* h, const double* amps) {
   return VQE_OK;
 }
 
+int vqe_set_init_state_dev(vqe_t* h, const void* dev_amps) {
+  if (!h || !dev_amps) return VQE_EINVAL;
+  HIP_TRY(h, hipSetDevice(h->dev));
+  const size_t dim = (size_t)1 << h->n;
+  HIP_TRY(h, h->init.reserve(dim));
+  HIP_TRY(h, hipMemcpyAsync(h->init.p, dev_amps, dim * 16, hipMemcpyDeviceToDevice, h->stream));
+  return VQE_OK;
+}
+
+int vqe_get_state_dev(vqe_t* h, const double* theta, void* dev_amps) {
+  if (!h) return VQE_EINVAL;
+  if (!dev_amps || (h->circ_params > 0 && !theta)) return fail(h, VQE_EINVAL, "bad arguments");
+  HIP_TRY(h, hipSetDevice(h->dev));
+  int rc = load_single(h, 1, theta);
+  if (rc) return rc;
+  const size_t dim = (size_t)1 << h->n;
+  HIP_TRY(h, h->d_state.reserve(dim));
+  if ((rc = run(h, 2, 0, 0, 0))) return rc;
+  HIP_TRY(h, hipMemcpyAsync(dev_amps, h->d_state.p, dim * 16, hipMemcpyDeviceToDevice, h->stream));
+  return VQE_OK;
+}
+
 int vqe_set_hamiltonian_pauli(vqe_t* h, int n_terms, const uint64_t* xmask, const uint64_t* zmask,
                               const double* coeff) {
   if (!h) return VQE_EINVAL;

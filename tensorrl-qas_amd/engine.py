@@ -109,6 +109,17 @@ class VQEEngine:
             raise ValueError("initial state has the wrong length")
         self._chk(self._lib.vqe_set_init_state(self._h, a.view(np.float64).ctypes.data_as(c_f64p)))
 
+    def set_init_state_dev(self, dev_ptr: int):
+        """Initial state from device memory (complex128[2^n]); asynchronous on the handle's stream."""
+        self._chk(self._lib.vqe_set_init_state_dev(self._h, C.c_void_p(int(dev_ptr))))
+
+    def get_state_dev(self, theta, dev_ptr: int):
+        """U(theta)|init> written to device memory (complex128[2^n]); asynchronous on the handle's stream."""
+        th = _f64(theta)
+        if th.size != self._P:
+            raise ValueError("theta has the wrong length")
+        self._chk(self._lib.vqe_get_state_dev(self._h, _p(th, c_f64p), C.c_void_p(int(dev_ptr))))
+
     def set_hamiltonian(self, xmask, zmask, coeff):
         x = np.ascontiguousarray(xmask, dtype=np.uint64)
         z = np.ascontiguousarray(zmask, dtype=np.uint64)

@@ -169,3 +169,253 @@ def fit_restarts_sharded(fit_shard, n_restarts_total: int, group=None):
         buf.copy_(torch.view_as_real(torch.as_tensor(np.ascontiguousarray(gates, np.complex128))))
     dist.broadcast(buf, src=owner, group=group)
     return float(vals[owner][0]), torch.view_as_complex(buf.cpu()).numpy().copy(), owner
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Amplitude-sharded STATES: a register of n qubits over world = 2^g ranks, 2^(n-g) amplitudes
+# each.  The top g positions of the physical index are the rank; a logical qubit sits at a position that the planner
+# tracks (pos[q]).  A gate whose qubits all sit at local positions needs no communication: a rank's shard is the
+# "state" of an (n-g)-qubit handle of the engine (vqe_set_init_state_dev / vqe_get_state_dev: it never leaves the GPU).
+# A gate - or the X / Y factor of a Pauli term - on a qubit at a rank position is preceded by a pairwise HALF-SHARD
+# EXCHANGE that swaps that position with a local one (rank r keeps the half of its shard whose local bit equals its
+# rank bit and trades the other half with rank r ^ bit: 2^(n-g-1) amplitudes each way, one xGMI link per pair); Z
+# factors on rank positions are signs.  The reference has no counterpart (single process; its 2^n x 2^n matrix stops
+# it at 13 qubits, environments/VQAs/VQE_qulacs_TN_notin_RL.py:86).
+# Status: the planner and the executor below are exercised by tests (gloo world 2 / 4 / 8 on the CPU with a CPU stand-in
+# as the local backend; all shards on ONE GPU with device-to-device copies as the exchange); no run on several GPUs
+# exists yet, so there is no scaling curve for it.
+def _log2_exact(v: int) -> int:
+    g = int(v).bit_length() - 1
+    if v < 1 or (1 << g) != v:
+        raise ValueError("world size of amplitude-sharded states must be a power of two")
+    return g
+
+
+class ShardStep:
+    """One step of a plan: ``kind`` = "gates" (``items`` = gate indices, all local under ``pos``), "energy" (``items`` =
+    term indices whose X support is local under ``pos``) or "swap" (``rank_bit`` <-> local position ``local_pos``)."""
+    __slots__ = ("kind", "items", "pos", "rank_bit", "local_pos")
+
+    def __init__(self, kind, items=None, pos=None, rank_bit=-1, local_pos=-1):
+        self.kind, self.items, self.pos, self.rank_bit, self.local_pos = kind, items, pos, rank_bit, local_pos
+
+
+def plan_amplitude_sharding(n: int, world: int, kind, q0, q1, xmask):
+    """Partition / exchange schedule for one circuit followed by the expectation sum of a Pauli Hamiltonian.
+
+    Greedy with look-ahead: a qubit is brought to a local position only when a gate (or the X support of a term)
+    needs it there, and the local qubit that gives way is the one whose next use lies farthest ahead.  Returns the
+    list of steps and the number of exchanges."""
+    g = _log2_exact(world)
+    nl = n - g
+    if nl < 1:
+        raise ValueError("more ranks than amplitudes pairs")
+    kind, q0, q1 = (np.asarray(a).astype(np.int64) for a in (kind, q0, q1))
+    G = kind.size
+    qubits = [[int(q0[i])] + ([int(q1[i])] if kind[i] in (0, 5) else []) for i in range(G)]
+    supports = [[q for q in range(n) if (int(x) >> q) & 1] for x in xmask]
+    if any(len(s) > nl for s in supports) or any(len(s) > nl for s in qubits):
+        raise ValueError("a gate or Pauli term touches more qubits than a shard holds")
+    pos = list(range(n))
+    steps, swaps = [], 0
+
+    def next_use(q, after):
+        for j in range(after, G):
+            if q in qubits[j]:
+                return j
+        # after the circuit: qubits that the Hamiltonian flips are wanted again, the others never
+        return G + (0 if any(q in s for s in supports) else 1)
+
+    def bring_local(q, keep, after):
+        nonlocal swaps
+        cand = [v for v in range(n) if pos[v] < nl and v not in keep]
+        victim = max(cand, key=lambda v: (next_use(v, after), -v))
+        steps.append(ShardStep("swap", rank_bit=pos[q] - nl, local_pos=pos[victim]))
+        pos[q], pos[victim] = pos[victim], pos[q]
+        swaps += 1
+
+    cur = []
+    for i in range(G):
+        need = [q for q in qubits[i] if pos[q] >= nl]
+        if need:
+            if cur:
+                steps.append(ShardStep("gates", items=cur, pos=list(pos)))
+                cur = []
+            for q in need:
+                bring_local(q, qubits[i], i + 1)
+        cur.append(i)
+    if cur:
+        steps.append(ShardStep("gates", items=cur, pos=list(pos)))
+    remaining = list(range(len(supports)))
+    while remaining:
+        local = [t for t in remaining if all(pos[q] < nl for q in supports[t])]
+        if local:
+            steps.append(ShardStep("energy", items=local, pos=list(pos)))
+            done = set(local)
+            remaining = [t for t in remaining if t not in done]
+            continue
+        # the term that needs the fewest exchanges next; qubits that the remaining terms still flip stay local if possible
+        t = min(remaining, key=lambda t: sum(pos[q] >= nl for q in supports[t]))
+        wanted = {}
+        for u in remaining:
+            for q in supports[u]:
+                wanted[q] = wanted.get(q, 0) + 1
+        for q in [q for q in supports[t] if pos[q] >= nl]:
+            cand = [v for v in range(n) if pos[v] < nl and v not in supports[t]]
+            victim = min(cand, key=lambda v: (wanted.get(v, 0), v))
+            steps.append(ShardStep("swap", rank_bit=pos[q] - nl, local_pos=pos[victim]))
+            pos[q], pos[victim] = pos[victim], pos[q]
+            swaps += 1
+    return steps, swaps
+
+
+class EngineShardBackend:
+    """Local arithmetic on the GPU: one (n - g)-qubit handle of the engine; shards are torch complex128 CUDA tensors
+    that the handle reads and writes in place (device-to-device on ONE stream, a torch stream of this object)."""
+
+    def __init__(self, n_local: int, device):
+        import torch
+        from .engine import VQEEngine, Circuit
+        self.torch, self.Circuit = torch, Circuit
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.Stream(device=self.device)
+        self.engine = VQEEngine(n_local, self.device.index or 0)
+        self.engine.set_stream(self.stream.cuda_stream)
+        self.n_local = n_local
+
+    def new_shard(self, values):
+        t = self.torch.as_tensor(np.ascontiguousarray(values, np.complex128)).to(self.device)
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        return t
+
+    def apply(self, shard, kind, q0, q1, pidx, theta):
+        out = self.torch.empty_like(shard)
+        with self.torch.cuda.stream(self.stream):
+            self.engine.set_init_state_dev(shard.data_ptr())
+            self.engine.set_circuit(self.Circuit(kind, q0, q1, pidx, len(theta)))
+            self.engine.get_state_dev(theta, out.data_ptr())
+        shard.record_stream(self.stream)
+        out.record_stream(self.stream)
+        return out
+
+    def energy(self, shard, xs, zs, cs):
+        if not len(xs):
+            return 0.0
+        with self.torch.cuda.stream(self.stream):
+            self.engine.set_init_state_dev(shard.data_ptr())
+            self.engine.set_hamiltonian(xs, zs, cs)
+            self.engine.set_circuit(self.Circuit.empty())
+            e = self.engine.energy(np.zeros(0))
+        return e
+
+    def halves(self, shard, local_pos):
+        return shard.view(-1, 2, 1 << local_pos)
+
+    def to_host(self, shard):
+        self.stream.synchronize()
+        return shard.cpu().numpy()
+
+    def close(self):
+        self.stream.synchronize()
+        self.engine.set_stream(None)
+        self.engine.close()
+
+
+class AmplitudeShardedState:
+    """Executor of a plan for the ranks this process holds: ``my_ranks`` = [rank] under torch.distributed (gloo in the
+    CPU tests, RCCL on GPUs: the halves travel as send / recv pairs between the two partners), or all ranks of the
+    world in ONE process (``my_ranks`` = range(world): the single-GPU emulation, exchange = device-to-device copy)."""
+
+    def __init__(self, n, world, my_ranks, backend, group=None):
+        self.n, self.world, self.g = n, world, _log2_exact(world)
+        self.nl = n - self.g
+        self.my_ranks = list(my_ranks)
+        self.backend = backend
+        self.group = group
+        self.shards = {}
+        self.exchanged_bytes = 0
+
+    def load(self, psi0):
+        """Initial state: this process keeps the slices [r 2^nl, (r+1) 2^nl) of its ranks (rank = top index bits)."""
+        psi0 = np.asarray(psi0, np.complex128)
+        for r in self.my_ranks:
+            self.shards[r] = self.backend.new_shard(psi0[r << self.nl:(r + 1) << self.nl])
+
+    def _exchange(self, k, local_pos):
+        bit = 1 << k
+        done = set()
+        for r in self.my_ranks:
+            if r in done:
+                continue
+            p = r ^ bit
+            b = (r >> k) & 1
+            mine = self.backend.halves(self.shards[r], local_pos)[:, 1 - b, :]
+            if p in self.shards:                                   # both partners live here: swap in place
+                theirs = self.backend.halves(self.shards[p], local_pos)[:, b, :]
+                tmp = mine.clone() if hasattr(mine, "clone") else mine.copy()
+                mine[...] = theirs
+                theirs[...] = tmp
+                done.add(p)
+                self.exchanged_bytes += int(np.prod(mine.shape)) * 16      # (the partner's half travels too)
+            else:
+                import torch
+                import torch.distributed as dist
+                t = mine if isinstance(mine, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(mine))
+                send = torch.view_as_real(t.contiguous()).clone()
+                recv = torch.empty_like(send)
+                if dist.get_backend(self.group) != "nccl" and send.is_cuda:
+                    send = send.cpu()
+                    recv = recv.cpu()
+                ops = [dist.P2POp(dist.isend, send, p, self.group), dist.P2POp(dist.irecv, recv, p, self.group)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                got = torch.view_as_complex(recv)
+                if isinstance(mine, torch.Tensor):
+                    mine.copy_(got.to(mine.device))
+                else:
+                    mine[...] = got.numpy()
+            self.exchanged_bytes += int(np.prod(mine.shape)) * 16
+            done.add(r)
+
+    def run(self, steps, kind, q0, q1, pidx, theta, xmask, zmask, coeff):
+        """Execute ``steps``; returns this process's part of <psi|H|psi> (the caller sums over processes)."""
+        kind, q0, q1, pidx = (np.asarray(a) for a in (kind, q0, q1, pidx))
+        theta = np.asarray(theta, np.float64)
+        xmask, zmask = np.asarray(xmask, np.uint64), np.asarray(zmask, np.uint64)
+        coeff = np.asarray(coeff)
+        nl, e = self.nl, 0.0
+        for st in steps:
+            if st.kind == "swap":
+                self._exchange(st.rank_bit, st.local_pos)
+            elif st.kind == "gates":
+                idx = np.asarray(st.items)
+                pos = np.asarray(st.pos)
+                k = kind[idx].astype(np.int32)
+                a = pos[q0[idx]].astype(np.int32)
+                two = (k == 0) | (k == 5)
+                b = np.where(two, pos[np.where(two, q1[idx], 0)], -1).astype(np.int32)
+                rot = (k >= 1) & (k <= 3)
+                th = theta[pidx[idx][rot]]
+                pl = np.where(rot, np.cumsum(rot) - 1, -1).astype(np.int32)
+                for r in self.my_ranks:
+                    self.shards[r] = self.backend.apply(self.shards[r], k, a, b, pl, th)
+            else:                       # energy of the terms whose X support is local: Z factors on rank bits are signs
+                pos = st.pos
+                for r in self.my_ranks:
+                    xs, zs, cs = [], [], []
+                    for t in st.items:
+                        x, z = int(xmask[t]), int(zmask[t])
+                        xl = zl = 0
+                        sign = 1.0
+                        for q in range(self.n):
+                            if (x >> q) & 1:
+                                xl |= 1 << pos[q]
+                            if (z >> q) & 1:
+                                if pos[q] < nl:
+                                    zl |= 1 << pos[q]
+                                elif (r >> (pos[q] - nl)) & 1:
+                                    sign = -sign
+                        xs.append(xl), zs.append(zl), cs.append(coeff[t] * sign)
+                    e += self.backend.energy(self.shards[r], np.array(xs, np.uint64), np.array(zs, np.uint64), np.array(cs))
+        return e

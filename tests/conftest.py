@@ -23,7 +23,7 @@ def golden_dir():
 # Collection order: the single-process parity suites first, the environment API next,
 # anything that starts other processes last - under the driver's `pytest -x` a harness-level failure of a
 # multi-process test must not hide the parity evidence of the core rows.
-_ORDER = ("test_hip_parity", "test_configs_gpu", "test_dm_gpu", "test_cobyla_emulation", "test_mps2qc_gpu", "test_step_traces",
+_ORDER = ("test_hip_parity", "test_configs_gpu", "test_dm_gpu", "test_amp_shard_gpu", "test_cobyla_emulation", "test_mps2qc_gpu", "test_step_traces",
           "test_env_gpu")
 _LAST = ("test_distributed_cpu", "test_zz_multirank_gpu")
 

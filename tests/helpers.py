@@ -145,3 +145,23 @@ def fermionic_hamiltonian(n, n_hop, n_quad, rng, dressed=0):
     keys = sorted(terms)
     return (np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64),
             np.array([terms[k] for k in keys], np.float64))
+
+
+class OracleShardBackend:
+    """Local arithmetic of the CPU tests of the amplitude-sharded states: the oracle stands in for the GPU (only the
+    sharding logic - plan, exchanges, signs of the rank bits - is under test; tensorrl_qas_amd.parallel)."""
+
+    def new_shard(self, values):
+        return np.ascontiguousarray(values, np.complex128).copy()
+
+    def apply(self, shard, kind, q0, q1, pidx, theta):
+        return vo.run_circuit(shard, kind, q0, q1, pidx, theta)
+
+    def energy(self, shard, xs, zs, cs):
+        return vo.energy_pauli(shard, xs, zs, cs) if len(xs) else 0.0
+
+    def halves(self, shard, local_pos):
+        return shard.reshape(-1, 2, 1 << local_pos)
+
+    def to_host(self, shard):
+        return np.asarray(shard)

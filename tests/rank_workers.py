@@ -148,7 +148,39 @@ def sharding_cpu(rank, world, port):
     return out
 
 
-WORKERS = {"sharded_gpu": sharded_gpu, "sharding_cpu": sharding_cpu}
+def amp_sharded_cpu(rank, world, port):
+    """CPU, gloo: amplitude-sharded STATES - every process holds one shard, the oracle is the local backend, the
+    half-shard exchanges really travel between the processes; one all-reduce sums the partial energies."""
+    dist = _setup(rank, world, port)
+    import numpy as np
+    import vqe_oracle as vo
+    import tensorrl_qas_amd as tq
+    from tensorrl_qas_amd import parallel
+    from helpers import OracleShardBackend, fermionic_hamiltonian, random_gates, random_state
+    out = {}
+    for n, seed, which in ((10, 0, "heisenberg"), (11, 1, "fermionic")):
+        rng = np.random.default_rng(seed)
+        psi0 = random_state(n, rng)
+        if which == "heisenberg":
+            hh, _ = tq.hamiltonian.heisenberg(n)
+            ham = (hh.xmask, hh.zmask, hh.coeff)
+        else:
+            ham = fermionic_hamiltonian(n, 8, 10, rng)
+        kind, q0, q1, pidx, th = random_gates(n, 30, rng)
+        steps, swaps = parallel.plan_amplitude_sharding(n, world, kind, q0, q1, ham[0])
+        st = parallel.AmplitudeShardedState(n, world, [rank], OracleShardBackend())
+        st.load(psi0)
+        part = st.run(steps, kind, q0, q1, pidx, th, *ham)
+        tot = parallel.allreduce_sum(np.array([part]))
+        ref = vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th), *ham)
+        out[which] = dict(total=float(tot[0]), ref=float(ref), swaps=int(swaps), bytes=int(st.exchanged_bytes),
+                          shard=int(st.shards[rank].size))
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+WORKERS = {"sharded_gpu": sharded_gpu, "sharding_cpu": sharding_cpu, "amp_sharded_cpu": amp_sharded_cpu}
 
 
 def main(argv):
