@@ -267,12 +267,12 @@ def mps2qc_aux(tq, dev, with_cpu):
                         "algorithmic_flop_per_step": 4 * G * (1 << n) * 32,
                         "note": "environments on v_mfma_f64_16x16x4_f64, gate sweeps on FP64 vector FMAs; "
                                 "both pipes peak at the same 78.6 TFLOP/s on MI355X; states LDS-resident"}}
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic_mps2qc.json")
-    if os.path.exists(tfile):      # HBM bytes per launch from a separate rocprofv3 --pmc run
-        tr = json.load(open(tfile))
-        if tr.get("workload") == out["workload"]:
-            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = tr["source"]
+    pm, why = load_pmc("mps2qc", out["workload"])      # HBM bytes per launch from separate rocprofv3 --pmc passes
+    if pm is not None and "FETCH_SIZE" in pm.get("per_launch", {}) and "WRITE_SIZE" in pm["per_launch"]:
+        out["roofline"]["traffic"] = (2.0 * pm["per_launch"]["FETCH_SIZE"] + pm["per_launch"]["WRITE_SIZE"]) * 1024.0
+        out["roofline"]["traffic_source"] = pm.get("source")
+    else:
+        out["roofline"]["traffic_note"] = why
     if with_cpu:      # the numpy restatement (oracle/stiefel_oracle.py) on one fit, a few steps
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import stiefel_oracle as so
@@ -346,13 +346,20 @@ def heis20_aux(tq, torch, dist, rank, world, dev, steps):
     tfile = os.path.join(ROOT, "profiles", "pmc_heis20.json")
     if os.path.exists(tfile):      # HBM bytes of one batched evaluation from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         tr = json.load(open(tfile))
-        if tr.get("workload") == "heisenberg_20q_77terms_G32_B256_sharded":
+        if tr.get("workload") == "heisenberg_20q_77terms_G32_B256_sharded" and tr.get("src_sha16") != src_sha16():
+            roof["note"] = f"profiles/pmc_heis20.json was measured on other sources ({tr.get('src_sha16')}): re-run tools/pmc_heis20.sh"
+        elif tr.get("workload") == "heisenberg_20q_77terms_G32_B256_sharded":
             per_batch = tr["hbm_bytes_per_batch"]
             gbs = per_batch * (evals_s / B) / 1e9
             roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                     "traffic": per_batch, "traffic_source": tr["source"],
                     "note": "measured HBM bytes of one batch of 256 evaluations (all k_t_* / k_s_* launches, one GPU) x batches/s of "
                             "this run; at N > 1 every rank moves the circuit part again, so this is the per-GPU figure at N = 1"}
+            # per kernel: bytes and duration of the same profiled batch (rocprofv3 --stats pass of tools/pmc_heis20.sh)
+            roof["kernels"] = {k: {"bound": "hbm", "achieved": v["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": (v["GBs"] / HBM_PEAK_GBS) if v.get("GBs") else None, "traffic": v["hbm_bytes_per_batch"],
+                                   "ms_per_batch": v["ms_per_batch"], "launches_per_batch": v["launches_per_batch"]}
+                               for k, v in tr.get("kernels", {}).items() if v.get("ms_per_batch")}
     roof["algorithmic"] = {"bytes_per_evaluation": bytes_per_eval, "mean_rotations": g_rot,
                            "GBs_if_every_gate_and_group_streamed": bytes_per_eval * evals_s / 1e9,
                            "note": "SURVEY 8d figure 2^n*16*(2 G_rot + T_x): informational - the LDS-tiled kernels apply several "
@@ -399,48 +406,85 @@ def launch_selftest(args, rank, world):
         dist.destroy_process_group()
 
 
-def pmc_roofline(workload, k_ms, evals_per_launch):
-    """Roofline of the LDS-resident kernel from rocprofv3 counters of THIS workload (profiles/pmc_lds_minimize.json,
-    written by tools/pmc.sh from separate --pmc passes): the executed FP64 vector flops, LDS-array cycles and HBM bytes
-    of one launch are properties of the workload (same seeds, same instruction stream); they are divided by the kernel
-    duration measured live in this run."""
-    path = os.path.join(ROOT, "profiles", "pmc_lds_minimize.json")
+def src_sha16():
+    """Hash of the kernel sources: a counter file describes ONE build (instruction counts are properties of the code),
+    so every profiles/pmc_*.json carries the hash of the sources it was measured on and is ignored when they moved on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "tensorrl-qas_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".h", ".hip", ".cpp")) or fn == "Makefile":
+            h.update(fn.encode())
+            h.update(open(os.path.join(csrc, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(key, workload):
+    """profiles/pmc_<key>.json (tools/pmc_collect.py: rocprofv3 --pmc passes over `bench.py --only <key>`) when it
+    belongs to this workload AND to the current sources; else (None, reason)."""
+    path = os.path.join(ROOT, "profiles", f"pmc_{key}.json")
     if not os.path.exists(path):
-        return None
-    pm = json.load(open(path))
+        return None, f"no profiles/pmc_{key}.json (tools/pmc_collect.py {key})"
+    try:
+        pm = json.load(open(path))
+    except ValueError:
+        return None, f"profiles/pmc_{key}.json is not valid JSON"
     if pm.get("workload") != workload:
-        return None
-    c = pm["per_launch"]
+        return None, f"profiles/pmc_{key}.json describes another workload ({pm.get('workload')})"
+    if pm.get("src_sha16") != src_sha16():
+        return None, f"profiles/pmc_{key}.json was measured on other sources ({pm.get('src_sha16')}, now {src_sha16()}): re-run tools/pmc_collect.py {key}"
+    return pm, None
+
+
+def counter_roofline(key, workload, kernel, k_ms, bound="fp64_valu", waves_per_unit=None, units_per_launch=None):
+    """Roofline object of one kernel from its counter file and the duration measured live in this run (HIP events).
+    fp64_valu: executed FP64 vector flops (2 FMA + MUL + ADD wave instructions x 64 lanes) / time against the 78.6 TFLOP/s
+    FP64 peak; hbm: measured HBM bytes ((2 FETCH_SIZE + WRITE_SIZE) x 1024, gfx950 read correction) / time against 8 TB/s.
+    Every missing counter is reported, never guessed."""
+    pm, why = load_pmc(key, workload)
+    peak, unit = (FP64_PEAK_TFLOPS, "TFLOP/s") if bound == "fp64_valu" else (HBM_PEAK_GBS, "GB/s")
+    out = {"bound": bound, "achieved": None, "peak": peak, "unit": unit, "frac": None, "traffic": None, "kernel": kernel,
+           "kernel_ms": k_ms}
+    if pm is None:
+        out["note"] = why
+        return out
+    c = pm.get("per_launch", {})
     sec = k_ms * 1e-3
-    flop = (2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]) * 64.0
-    hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0        # gfx950: FETCH_SIZE counts half of wide reads
-    out = {"bound": "fp64_valu", "achieved": flop / sec / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": flop / sec / 1e12 / FP64_PEAK_TFLOPS, "traffic": hbm,
-           "flop_per_launch": flop, "flop_per_evaluation": flop / pm["evaluations_per_launch"],
-           "source": pm["source"],
-           "note": "executed FP64 vector flops (2 FMA + MUL + ADD wave instructions x 64 lanes) of one launch / kernel "
-                   "duration of this run; the state never leaves VGPRs / LDS, so neither HBM nor MFMA binds - the FP64 "
-                   "vector pipe peaks at the same 78.6 TFLOP/s as the FP64 matrix pipe on MI355X",
-           "hbm": {"achieved": hbm / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / sec / 1e9 / HBM_PEAK_GBS},
-           "fp64_share_of_wave_instructions": (c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"])
-           / max(1.0, c.get("SQ_INSTS_ALL", 0.0)) if c.get("SQ_INSTS_ALL") else None}
-    if c.get("SQ_INSTS_ALL") and c.get("SQ_WAVE_CYCLES"):
-        waves = 4.0 * pm["evaluations_per_launch"]      # 4 wavefronts per workgroup, one workgroup per evaluation stream
-        out["issue"] = {"wave_instructions_per_evaluation": c["SQ_INSTS_ALL"] / waves,
-                        "of_which_fp64_valu": (c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]) / waves,
-                        "wave_cycles_instruction_active": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
-                        "wave_cycles_waiting_on_counter": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
-                        "wave_cycles_waiting_for_issue": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
-                        "note": "SQ_* sums of the same counter file (quad-cycles of all waves): what bounds the kernel is "
-                                "instruction issue at 2 waves per SIMD (LDS-limited occupancy), DESIGN.md 4.1"}
-    if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
-        # LDS-array cycles summed over the CUs / (CUs x kernel cycles): utilisation of the LDS pipes
-        cus = pm.get("cu_count", 256)
-        xcds = pm.get("xcd_count", 8)      # GRBM_GUI_ACTIVE is summed over the XCDs, SQ_* over all CUs
+    need = ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64")
+    flop = (2.0 * c[need[0]] + c[need[1]] + c[need[2]]) * 64.0 if all(k in c for k in need) else None
+    hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
+    out["source"] = pm.get("source")
+    out["kernel_ms_under_rocprof"] = pm.get("kernel_ms_avg")
+    out["traffic"] = hbm
+    missing = [k for k in need if k not in c] if bound == "fp64_valu" else [k for k in ("FETCH_SIZE", "WRITE_SIZE") if k not in c]
+    if missing:
+        out["note"] = "counter file lacks " + ", ".join(missing)
+        return out
+    if bound == "fp64_valu":
+        out.update(achieved=flop / sec / 1e12, frac=flop / sec / 1e12 / FP64_PEAK_TFLOPS, flop_per_launch=flop)
+        if hbm is not None:
+            out["hbm"] = {"achieved": hbm / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / sec / 1e9 / HBM_PEAK_GBS}
+    else:
+        out.update(achieved=hbm / sec / 1e9, frac=hbm / sec / 1e9 / HBM_PEAK_GBS)
+        if flop is not None:
+            out["fp64"] = {"achieved": flop / sec / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / sec / 1e12 / FP64_PEAK_TFLOPS}
+    if units_per_launch:
+        out["flop_per_evaluation" if bound == "fp64_valu" else "bytes_per_unit"] = (flop if bound == "fp64_valu" else hbm) / units_per_launch
+    if c.get("SQ_INSTS_ALL") and c.get("SQ_WAVE_CYCLES") and waves_per_unit and units_per_launch:
+        waves = float(waves_per_unit) * units_per_launch
+        f64 = sum(c.get(k, 0.0) for k in need)
+        out["issue"] = {"wave_instructions_per_evaluation": c["SQ_INSTS_ALL"] / waves, "of_which_fp64_valu": f64 / waves,
+                        "of_which_valu": c.get("SQ_INSTS_VALU", 0.0) / waves,
+                        "fp64_share_of_wave_instructions": f64 / c["SQ_INSTS_ALL"],
+                        "wave_cycles_instruction_active": c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
+                        "wave_cycles_waiting_on_counter": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
+                        "wave_cycles_waiting_for_issue": c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]}
+    if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]:
+        cus, xcds = pm.get("cu_count", 256), pm.get("xcd_count", 8)   # GRBM_GUI_ACTIVE is summed over the XCDs, SQ_* over all CUs
         out["lds"] = {"array_cycles_per_launch": c["SQ_LDS_IDX_ACTIVE"], "bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"),
-                      "frac": c["SQ_LDS_IDX_ACTIVE"] / (cus * c["GRBM_GUI_ACTIVE"] / xcds),
-                      "note": "SQ_LDS_IDX_ACTIVE / (CUs x kernel cycles): share of cycles the LDS arrays are busy "
-                              "(kernel cycles = GRBM_GUI_ACTIVE / XCDs)"}
+                      "frac": c["SQ_LDS_IDX_ACTIVE"] / (cus * c["GRBM_GUI_ACTIVE"] / xcds)}
+        if "SQ_INSTS_VALU" in c:
+            out["valu_busy_frac"] = 4.0 * c["SQ_INSTS_VALU"] / (4.0 * cus * c["GRBM_GUI_ACTIVE"] / xcds)   # 4 cycles per wave64 VALU op, 4 SIMDs per CU
     return out
 
 
@@ -550,9 +594,12 @@ def noisy_aux(tq, n, ham, psi0, batch, B, G, maxfun):
         eng.sync()
     ms = eng.last_kernel_ms()
     _, f, nfev = eng.batch_fetch(want_x=False)
-    return {"workload": f"lih12_synthetic631_fixed_noise_p1_0.01_p2_0.05_G{G}_B{B}", "env_steps_per_s_per_gpu": B / (ms * 1e-3),
-            "evals_per_s_per_gpu": float(nfev.sum() + B) / (ms * 1e-3), "mean_nfev": float(nfev.mean()), "kernel_ms": ms,
-            "mean_energy": float(np.mean(f)), "noise": "Pauli trajectories, one draw per (environment, evaluation, gate)"}
+    workload = f"lih12_synthetic631_fixed_noise_p1_0.01_p2_0.05_G{G}_B{B}"
+    evals = float(nfev.sum() + B)
+    return {"workload": workload, "env_steps_per_s_per_gpu": B / (ms * 1e-3),
+            "evals_per_s_per_gpu": evals / (ms * 1e-3), "mean_nfev": float(nfev.mean()), "kernel_ms": ms,
+            "mean_energy": float(np.mean(f)), "noise": "Pauli trajectories, one draw per (environment, evaluation, gate)",
+            "roofline": counter_roofline("noisy12", workload, "k_lds_minimize<12, false, true>", ms, "fp64_valu", 4, evals)}
 
 
 def trainable8_aux(tq, B=4096, G=150, maxfun=300):
@@ -580,9 +627,135 @@ def trainable8_aux(tq, B=4096, G=150, maxfun=300):
         eng.sync()
     ms = eng.last_kernel_ms()
     _, f, nfev = eng.batch_fetch(want_x=False)
-    return {"workload": f"h2o8_193terms_trainable_regime_G{G}_P{rot.sum(1).mean():.0f}_B{B}_maxfun{maxfun}",
-            "evals_per_s_per_gpu": float(nfev.sum()) / (ms * 1e-3), "minimisations_per_s_per_gpu": B / (ms * 1e-3),
-            "mean_nfev": float(nfev.mean()), "kernel_ms": ms, "kernel": "k_lds_minimize<8>", "mean_energy": float(np.mean(f))}
+    workload = f"h2o8_193terms_trainable_regime_G{G}_P{rot.sum(1).mean():.0f}_B{B}_maxfun{maxfun}"
+    evals = float(nfev.sum())
+    return {"workload": workload,
+            "evals_per_s_per_gpu": evals / (ms * 1e-3), "minimisations_per_s_per_gpu": B / (ms * 1e-3),
+            "mean_nfev": float(nfev.mean()), "kernel_ms": ms, "kernel": "k_lds_minimize<8>", "mean_energy": float(np.mean(f)),
+            "roofline": counter_roofline("trainable8", workload, "k_lds_minimize<8, false, false>", ms, "fp64_valu", 1, evals)}
+
+
+def trainable12_aux(tq, B=512, maxfun=1000):
+    """BASELINE config 2 at the size the README's table names for TensorRL_trainable/LIH12q_TNbond2 (203 rotations + 37
+    CNOTs from |0...0>, every committed rotation a variable; reference environment_qulacs.py:285-328,417-445): fused
+    env-step with the workgroup-wide optimiser update on 2 x 208^2 matrices per environment (695 KB, L2 / HBM)."""
+    n = 12
+    ham = tq.hamiltonian.synthetic_lih12()
+    eng = tq.VQEEngine(n)
+    eng.set_hamiltonian(ham.xmask, ham.zmask, ham.coeff)
+    rng = np.random.default_rng(1203)
+    circs, ths, new = [], [], []
+    for b in range(B):
+        kind = np.array([0] * 37 + list(rng.integers(1, 4, 203)), np.int32)
+        rng.shuffle(kind)
+        q0 = rng.integers(0, n, kind.size).astype(np.int32)
+        q1 = np.where(kind == 0, (q0 + 1 + rng.integers(0, n - 1, kind.size)) % n, -1).astype(np.int32)
+        pidx = np.where(kind > 0, np.cumsum(kind > 0) - 1, -1).astype(np.int32)
+        th = rng.uniform(-np.pi, np.pi, 203).astype(np.float32).astype(np.float64)
+        last = int(np.nonzero(kind > 0)[0][-1])
+        th[pidx[last]] = 0.0
+        circs.append(tq.Circuit(kind, q0, q1, pidx, 203)), ths.append(th), new.append(last)
+    eng.batch_load(circs, ths)
+    eng.batch_set_new_gate(new)
+    for _ in range(2):
+        eng.batch_run_env_step(1.0, 1e-4, maxfun)
+        eng.sync()
+    ms = eng.last_kernel_ms()
+    _, f, nfev = eng.batch_fetch(want_x=False)
+    evals = float(nfev.sum() + B)
+    workload = f"lih12_synthetic631_trainable_regime_G240_P202_B{B}_maxfun{maxfun}"
+    return {"workload": workload, "evals_per_s_per_gpu": evals / (ms * 1e-3), "env_steps_per_s_per_gpu": B / (ms * 1e-3),
+            "mean_nfev": float(nfev.mean()), "kernel_ms": ms, "kernel": "k_lds_minimize<12, true, false>",
+            "mean_energy": float(np.mean(f)),
+            "roofline": counter_roofline("trainable12", workload, "k_lds_minimize<12, true, false>", ms, "fp64_valu", 4, evals)}
+
+
+def dm_aux(tq, n, ham, psi0, batch, G, n_circ=4):
+    """BASELINE config 5 in the EXACT channel mode (vqe_set_noise_mode(1)): the bench circuits with a depolarising channel
+    behind every gate, density matrix of 4^n complex128 (268 MB at 12 qubits), superoperator blocks applied with
+    v_mfma_f64_16x16x4_f64 (csrc/vqe_dm.h).  A block sweep reads and writes rho once: algorithmic bytes per evaluation =
+    (2 blocks + 1) x 4^n x 16 B; time = device time of the launches (HIP events; the host forms the blocks in between)."""
+    B = n_circ
+    k = batch["kind"].reshape(-1, G)[:B]; q0 = batch["q0"].reshape(-1, G)[:B]; q1 = batch["q1"].reshape(-1, G)[:B]
+    p = batch["pidx"].reshape(-1, G)[:B]
+    k2 = np.empty((B, 2 * G), np.int32); a2 = np.empty_like(k2); b2 = np.empty_like(k2); p2 = np.empty_like(k2)
+    k2[:, 0::2] = k; k2[:, 1::2] = np.where(k == 0, 5, 4)
+    a2[:, 0::2] = q0; a2[:, 1::2] = q0
+    b2[:, 0::2] = q1; b2[:, 1::2] = np.where(k == 0, q1, -1)
+    p2[:, 0::2] = p; p2[:, 1::2] = -1
+    eng = tq.VQEEngine(n)
+    eng.set_init_state(psi0)
+    eng.set_hamiltonian(ham.xmask, ham.zmask, ham.coeff)
+    eng.set_noise(0.01, 0.05, 7)
+    eng.set_noise_mode(1)
+    par_off = batch["par_off"][:B + 1]
+    eng.batch_load_flat(np.arange(B + 1, dtype=np.int64) * 2 * G, k2.ravel(), a2.ravel(), b2.ravel(), p2.ravel(),
+                        par_off, batch["theta"][:par_off[-1]])
+    t0 = time.perf_counter()
+    for _ in range(2):
+        eng.batch_run_energy()
+        eng.sync()
+    wall = (time.perf_counter() - t0) / 2
+    ms = eng.last_kernel_ms()
+    _, f, _ = eng.batch_fetch(want_x=False)
+    blocks = eng.noise_mode_info()["blocks_last_evaluation"]
+    byt = B * (2.0 * blocks + 1.0) * (4.0 ** n) * 16.0         # (the last circuit's block count stands for all: same generator)
+    gbs = byt / (ms * 1e-3) / 1e9
+    workload = f"lih12_synthetic631_fixed_noise_exact_channel_G{G}_B{B}"
+    roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "k_dm_block", "kernel_ms": ms, "algorithmic_bytes": byt,
+            "note": "algorithmic bytes (one read + one write of rho per block sweep, one write by the init) / device time of "
+                    "the launches of this run"}
+    pm, why = load_pmc("dm12", workload)
+    if pm is not None and "FETCH_SIZE" in pm.get("per_launch", {}) and "WRITE_SIZE" in pm["per_launch"]:
+        c = pm["per_launch"]
+        roof["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0       # per k_dm_block launch
+        roof["traffic_per"] = "k_dm_block launch (algorithmic: %.0f)" % (2.0 * (4.0 ** n) * 16.0)
+        roof["source"] = pm.get("source")
+    else:
+        roof["traffic_note"] = why
+    return {"workload": workload, "evals_per_s_device": B / (ms * 1e-3), "evals_per_s_wall": B / wall, "blocks_per_evaluation": blocks,
+            "kernel_ms": ms, "mean_energy": float(np.mean(f)), "roofline": roof,
+            "note": "exact tr(rho H) of the channel the trajectory sampler (noisy12) draws from"}
+
+
+def mps2qc_stream_aux(tq, dev):
+    """The HBM-streaming MPS -> PQC fit (mps2qc_fit_brickwork_stream, beyond the 12 qubits of the LDS-resident kernel):
+    18 qubits, one brickwork layer (17 SU(4) gates), 30 Stiefel-Adam steps of one fit.  Per step the kernels sweep the two
+    work vectors: G forward applications (read + write psi) and G fused backward sweeps (read + write psi and phi):
+    algorithmic bytes per step = G x 96 x 2^n."""
+    from tensorrl_qas_amd import dmrg_to_qc as dq
+    n, layers, iters = 18, 1, 30
+    rng = np.random.default_rng(1818)
+    sites, G = dq.brickwork_ansatz(n, layers)
+    v = rng.normal(size=1 << n) + 1j * rng.normal(size=1 << n)
+    target = v / np.linalg.norm(v)
+    init = np.array([dq.rand_uni(4, rng) for _ in range(G)])
+    opt = dq.StiefelAdam(3e-3, 0.9, 0.999, 1e-8, jit_frozen=True, device_id=dev, stream=True)
+    prob = dq.BrickworkOverlap(n, sites, target)
+    opt.minimize(prob, init, max_iter=iters, tol=0.0, param_tol=0.0)
+    t0 = time.perf_counter()
+    opt.minimize(prob, init, max_iter=iters, tol=0.0, param_tol=0.0)
+    wall = time.perf_counter() - t0
+    steps = int(np.sum(opt.n_iter))
+    byt = steps * G * 96.0 * (1 << n)
+    ms = opt.kernel_ms
+    gbs = byt / (ms * 1e-3) / 1e9
+    workload = f"brickwork_fit_stream_{n}q_{layers}layer_G{G}_iters{iters}"
+    roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "k_sf_apply + k_sf_back", "kernel_ms": ms, "algorithmic_bytes": byt,
+            "note": "algorithmic bytes G x 96 x 2^n per step / device time reported by the library"}
+    pm, why = load_pmc("mps2qc_stream", workload)
+    if pm is not None and "FETCH_SIZE" in pm.get("per_launch", {}) and "WRITE_SIZE" in pm["per_launch"]:
+        c = pm["per_launch"]
+        roof["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 * pm.get("launches", 1) / 2.0     # per minimize() call (two calls per run)
+        roof["traffic_per"] = "fit of %d steps" % steps
+        roof["source"] = pm.get("source")
+    else:
+        roof["traffic_note"] = why
+    return {"workload": workload, "optimiser_steps_per_s_device": steps / (ms * 1e-3), "optimiser_steps_per_s_wall": steps / wall,
+            "kernel_ms": ms, "final_loss": float(opt.loss_history[-1]),
+            "roofline": roof, "note": "one launch per gate and step, Stiefel-Adam update on the host: not tuned (DESIGN 4.5)"}
 
 
 def main():
@@ -611,9 +784,18 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="only the timed launches of the headline kernel (profiling "
                     "runs: no warm-start / sweep / episode / heis20 / mps2qc / cpu_baseline launches in the trace)")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU rehearsal of the multi-rank launch path (no GPU work)")
+    ap.add_argument("--only", default=None, choices=["headline", "noisy12", "trainable8", "trainable12", "dm12", "mps2qc",
+                                                      "mps2qc_stream", "heis20"],
+                    help="run ONE object of the bench line and print it (tools/pmc_collect.py profiles these commands)")
+    ap.add_argument("--no-trainable12", action="store_true")
+    ap.add_argument("--no-dm", action="store_true")
+    ap.add_argument("--no-mps2qc-stream", action="store_true")
     args = ap.parse_args()
+    if args.only == "headline":
+        args.headline_only = True
     if args.headline_only:
         args.no_cpu_baseline = args.no_heis20 = args.no_mps2qc = args.no_sweep = args.no_episode = args.no_noisy = args.no_trainable8 = args.no_episode8 = True
+        args.no_trainable12 = args.no_dm = args.no_mps2qc_stream = True
 
     # ---- launch: under torchrun every process is a rank; started plainly with --gpus N > 1 this process
     # spawns the ranks itself, before anything touches the GPU
@@ -659,6 +841,28 @@ def main():
     eng.batch_load_flat(batch["gate_off"], batch["kind"], batch["q0"], batch["q1"], batch["pidx"],
                         batch["par_off"], batch["theta"])
     eng.batch_set_new_gate(batch["new_gate"])
+
+    if args.only and args.only != "headline":      # one object of the line (profiling commands)
+        if args.only == "noisy12":
+            obj = noisy_aux(tq, n, ham, psi0, batch, B, G, args.maxfun)
+        elif args.only == "trainable8":
+            obj = trainable8_aux(tq)
+        elif args.only == "trainable12":
+            obj = trainable12_aux(tq)
+        elif args.only == "dm12":
+            obj = dm_aux(tq, n, ham, psi0, batch, G)
+        elif args.only == "mps2qc":
+            obj = mps2qc_aux(tq, local, False)
+        elif args.only == "mps2qc_stream":
+            obj = mps2qc_stream_aux(tq, local)
+        else:
+            obj = heis20_aux(tq, torch, dist, rank, world, local, max(2, args.steps))
+        if rank == 0:
+            print(json.dumps({"only": args.only, **obj}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     def step():
         eng.batch_run_env_step(1.0, 1e-4, args.maxfun)
@@ -710,6 +914,8 @@ def main():
     sweep = None if args.no_sweep else g_sweep(tq, eng, n, B, args.maxfun, rank)
     noisy = None if (args.no_noisy or rank != 0) else noisy_aux(tq, n, ham, psi0, batch, B, G, args.maxfun)
     train8 = None if (args.no_trainable8 or rank != 0) else trainable8_aux(tq)
+    train12 = None if (args.no_trainable12 or rank != 0) else trainable12_aux(tq)
+    dm12 = None if (args.no_dm or rank != 0) else dm_aux(tq, n, ham, psi0, batch, G)
 
     episode = None
     if not args.no_episode and rank == 0 and world == 1:
@@ -726,11 +932,20 @@ def main():
 
     if rank == 0:
         workload = f"lih12_synthetic631_fixed_noiseless_G{G}_B{B}_per_gpu"
-        roof = pmc_roofline(workload, k_ms, evals_per_launch)
-        if roof is None:      # no counter file for this workload: say so instead of inventing a fraction
-            roof = {"bound": "fp64_valu", "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                    "traffic": None, "note": "no profiles/pmc_lds_minimize.json for this workload (tools/pmc.sh)"}
-        roof.update({"kernel": "k_lds_minimize<12>", "kernel_ms": k_ms, "evaluations_per_launch": evals_per_launch,
+        roof = counter_roofline("headline", workload, "k_lds_minimize<12, false, false>", k_ms, "fp64_valu", 4, evals_per_launch)
+        roof.setdefault("note", "executed FP64 vector flops (2 FMA + MUL + ADD wave instructions x 64 lanes) of one launch / kernel "
+                        "duration of this run; the state never leaves VGPRs / LDS, so neither HBM nor MFMA binds - the FP64 vector "
+                        "pipe peaks at the same 78.6 TFLOP/s as the FP64 matrix pipe on MI355X.  The energy step skips the exact "
+                        "zeros of the sign-sum tables (unit path, round 3): fewer flops are EXECUTED per evaluation than in "
+                        "rounds 1-2 (dense_equivalent below is the old kernel's flop count over this run's time)")
+        if roof.get("achieved") is not None:
+            # the flops the round-2 kernel executed for the same workload (profiles/r02g_pmc_sq.txt: 7.254e12 per launch of
+            # 4 100 061 evaluations), at this run's rate: comparable with the fractions of rounds 1 and 2
+            dense = 7.254e12 / 4100061.0 * evals_per_launch
+            roof["dense_equivalent"] = {"flop_per_launch": dense, "achieved": dense / (k_ms * 1e-3) / 1e12,
+                                        "frac": dense / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                        "note": "NOT executed work: the round-2 kernel's flops for these evaluations / this run's time"}
+        roof.update({"evaluations_per_launch": evals_per_launch,
                      "algorithmic": {"bytes_per_evaluation": bytes_per_eval, "bytes_per_evaluation_xgrouped": bytes_per_eval_grouped,
                                      "GBs_if_streamed_from_hbm": evals_per_launch * bytes_per_eval / (k_ms * 1e-3) / 1e9,
                                      "note": "SURVEY 8d figure 2^n*16*(2G+T) x evaluations / kernel time: what a kernel that "
@@ -758,6 +973,10 @@ def main():
             out["noisy12"] = noisy
         if train8 is not None:
             out["trainable8"] = train8
+        if train12 is not None:
+            out["trainable12"] = train12
+        if dm12 is not None:
+            out["dm12"] = dm12
         if episode is not None:
             out["episode"] = episode
         if episode8 is not None:
@@ -766,6 +985,8 @@ def main():
             out["heis20"] = heis
         if not args.no_mps2qc:
             out["mps2qc"] = mps2qc_aux(tq, local, not args.no_cpu_baseline and world == 1)
+        if not args.no_mps2qc_stream:
+            out["mps2qc_stream"] = mps2qc_stream_aux(tq, local)
         if not args.no_cpu_baseline and world == 1:      # timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(tq, ham, psi0, batch, G, args.cpu_steps, args.maxfun)
         print(json.dumps(out), flush=True)

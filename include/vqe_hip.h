@@ -121,6 +121,9 @@ int vqe_set_noise(vqe_t* h, double p1, double p2, uint64_t seed);
  * vqe_batch_run_minimize / _env_step (COBYLA then driven by the host on the exact energies).  The seed of
  * vqe_set_noise and vqe_set_shot_noise play no part in mode 1. */
 int vqe_set_noise_mode(vqe_t* h, int mode);
+/* out[0] = the mode, out[1] = superoperator blocks (sweeps over rho) of the last exact-mode evaluation; for the
+ * caller's roofline arithmetic (a sweep reads and writes 4^n complex128) */
+int vqe_noise_mode_info(vqe_t* h, int32_t out[2]);
 /* Finite-shot model of the reference's restricted variant
  * (environments/VQAs/VQE_qulacs_TN_notin_RL_noise_restricted.py:47-48,84-96): every evaluation
  * returns E + weights . N(0, sigma^2 I), sigma = n_shots^-1/2, i.e. E + sigma_total * N(0,1)

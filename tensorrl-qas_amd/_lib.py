@@ -39,6 +39,7 @@ SIGNATURES = {
     "vqe_hamiltonian_terms": (C.c_int, [vp, c_i32p, c_i32p]),
     "vqe_hamiltonian_layout": (C.c_int, [vp, c_i32p]),
     "vqe_set_noise_mode": (C.c_int, [vp, C.c_int]),
+    "vqe_noise_mode_info": (C.c_int, [vp, c_i32p]),
     "vqe_set_init_state_dev": (C.c_int, [vp, vp]),
     "vqe_get_state_dev": (C.c_int, [vp, c_f64p, vp]),
     "vqe_set_term_shard": (C.c_int, [vp, C.c_int, C.c_int]),

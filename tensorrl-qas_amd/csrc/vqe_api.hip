@@ -103,7 +103,10 @@ struct vqe_handle {
   DevBuf<double> dm_S, dm_partial, dm_cr, dm_ci;
   DevBuf<uint32_t> dm_gx, dm_tz;
   DevBuf<int32_t> dm_toff;
-  int dm_groups = 0;
+  int dm_groups = 0, dm_blocks_last = 0;
+  float dm_gpu_ms = 0.f;       // device time of the last exact-mode run (init + block sweeps + tr(rho H)), summed over its evaluations
+  bool last_run_dm = false;
+  hipEvent_t dm_ev0 = nullptr, dm_ev1 = nullptr;
   uint64_t dm_ham_gen = ~0ull;
   DevBuf<double> d_cob_x0, d_cob_xres, d_cob_f;      // device-resident lock-step COBYLA of the streaming path
   DevBuf<int32_t> d_cob_nfev, d_cob_active;
@@ -1130,6 +1133,8 @@ int dm_energy_one(vqe_t* h, const GateRec* g, int G, const double* theta, double
   int rc;
   if ((rc = upload(h, h->dm_S, S.data(), S.size()))) return rc;
   const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, (size_t)h->cu_count * 16);
+  if (!h->dm_ev0) { HIP_TRY(h, hipEventCreate(&h->dm_ev0)); HIP_TRY(h, hipEventCreate(&h->dm_ev1)); }
+  HIP_TRY(h, hipEventRecord(h->dm_ev0, h->stream));
   hipLaunchKernelGGL(k_dm_init, dim3(grid), dim3(256), 0, h->stream, h->dm_rho.p, (const double2*)h->init.p, n);
   for (size_t k = 0; k < blocks.size(); ++k) {
     DmBlockArgs A{};
@@ -1147,8 +1152,13 @@ int dm_energy_one(vqe_t* h, const GateRec* g, int G, const double* theta, double
                      (const double*)h->dm_cr.p, (const double*)h->dm_ci.p, h->dm_partial.p);
   hipLaunchKernelGGL(k_dm_sum, dim3(1), dim3(64), 0, h->stream, (const double*)h->dm_partial.p, eb, h->dm_partial.p + eb);
   HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipEventRecord(h->dm_ev1, h->stream));
   HIP_TRY(h, hipMemcpyAsync(e_host, h->dm_partial.p + eb, 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));      // (S and the blocks go out of scope)
+  float ms = 0.f;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->dm_ev0, h->dm_ev1));
+  h->dm_gpu_ms += ms;
+  h->dm_blocks_last = (int)blocks.size();
   return VQE_OK;
 }
 
@@ -1160,6 +1170,8 @@ int dm_run(vqe_t* h, int which, const BatchArgs& A) {
   int rc = dm_prepare_ham(h);
   if (rc) return rc;
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  h->dm_gpu_ms = 0.f;
+  h->last_run_dm = true;
   const int B = h->batch;
   std::vector<double> f(B, 0.0), x(h->h_theta), xraw(h->h_theta);
   std::vector<int32_t> nfev(B, 1);
@@ -1251,6 +1263,7 @@ int run(vqe_t* h, int which, double rhobeg, double rhoend, int maxfun) {
     A.trace = h->d_trace.p;
     h->trace_maxfun = maxfun; h->trace_stride = (int)stride; h->trace_batch = h->batch;
   }
+  h->last_run_dm = false;
   if (h->noise_mode == 1 && (which == 0 || which == 1 || which == 3)) return dm_run(h, which == 0 ? 0 : 1, A);
   if (h->lds_path) rc = dispatch_lds(h, which, A);
   else rc = stream_run(h, which, A);
@@ -1303,6 +1316,8 @@ void vqe_destroy(vqe_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->dev);
   (void)hipStreamSynchronize(h->stream);
+  if (h->dm_ev0) (void)hipEventDestroy(h->dm_ev0);
+  if (h->dm_ev1) (void)hipEventDestroy(h->dm_ev1);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1498,6 +1513,13 @@ int vqe_set_noise_mode(vqe_t* h, int mode) {
   if (mode != 0 && mode != 1) return fail(h, VQE_EINVAL, "noise mode: 0 (Pauli trajectories) or 1 (exact channel)");
   if (mode == 1 && (h->n < 2 || h->n > 13)) return fail(h, VQE_EINVAL, "the exact channel mode (density matrix) serves 2 <= n_qubits <= 13");
   h->noise_mode = mode;
+  return VQE_OK;
+}
+
+int vqe_noise_mode_info(vqe_t* h, int32_t out[2]) {
+  if (!h || !out) return VQE_EINVAL;
+  out[0] = h->noise_mode;
+  out[1] = h->dm_blocks_last;
   return VQE_OK;
 }
 
@@ -1710,6 +1732,7 @@ int vqe_debug_counters(vqe_t* h, uint64_t out[8]) {
 
 int vqe_last_kernel_ms(vqe_t* h, float* ms) {
   if (!h || !ms) return VQE_EINVAL;
+  if (h->last_run_dm) { *ms = h->dm_gpu_ms; return VQE_OK; }      // exact channel mode: device time only (the host builds the blocks in between)
   HIP_TRY(h, hipEventSynchronize(h->ev1));
   HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
   return VQE_OK;

@@ -159,6 +159,11 @@ class VQEEngine:
         """0: Pauli trajectories (one draw per evaluation); 1: the exact channel (density matrix, n <= 13)."""
         self._chk(self._lib.vqe_set_noise_mode(self._h, int(mode)))
 
+    def noise_mode_info(self):
+        out = (C.c_int32 * 2)()
+        self._chk(self._lib.vqe_noise_mode_info(self._h, out))
+        return {"mode": out[0], "blocks_last_evaluation": out[1]}
+
     def set_shot_noise(self, sigma_total: float, seed: int):
         self._chk(self._lib.vqe_set_shot_noise(self._h, float(sigma_total), C.c_uint64(int(seed) & (2 ** 64 - 1))))
 
