@@ -359,7 +359,7 @@ def heis20_aux(tq, torch, dist, rank, world, dev, steps):
             roof["kernels"] = {k: {"bound": "hbm", "achieved": v["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": (v["GBs"] / HBM_PEAK_GBS) if v.get("GBs") else None, "traffic": v["hbm_bytes_per_batch"],
                                    "ms_per_batch": v["ms_per_batch"], "launches_per_batch": v["launches_per_batch"]}
-                               for k, v in tr.get("kernels", {}).items() if v.get("ms_per_batch")}
+                               for k, v in tr.get("kernels", {}).items() if v.get("ms_per_batch") and ("k_t_ops" in k or "k_t_energy" in k)}
     roof["algorithmic"] = {"bytes_per_evaluation": bytes_per_eval, "mean_rotations": g_rot,
                            "GBs_if_every_gate_and_group_streamed": bytes_per_eval * evals_s / 1e9,
                            "note": "SURVEY 8d figure 2^n*16*(2 G_rot + T_x): informational - the LDS-tiled kernels apply several "
@@ -412,8 +412,9 @@ def src_sha16():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "tensorrl-qas_amd", "csrc")
+    # the DEVICE sources and the build flags (vqe_api.hip and vec_env.cpp are host code: launch plumbing, planners)
     for fn in sorted(os.listdir(csrc)):
-        if fn.endswith((".h", ".hip", ".cpp")) or fn == "Makefile":
+        if fn.endswith(".h") or fn in ("mps2qc_fit.hip", "Makefile"):
             h.update(fn.encode())
             h.update(open(os.path.join(csrc, fn), "rb").read())
     return h.hexdigest()[:16]
@@ -632,7 +633,7 @@ def trainable8_aux(tq, B=4096, G=150, maxfun=300):
     return {"workload": workload,
             "evals_per_s_per_gpu": evals / (ms * 1e-3), "minimisations_per_s_per_gpu": B / (ms * 1e-3),
             "mean_nfev": float(nfev.mean()), "kernel_ms": ms, "kernel": "k_lds_minimize<8>", "mean_energy": float(np.mean(f)),
-            "roofline": counter_roofline("trainable8", workload, "k_lds_minimize<8, false, false>", ms, "fp64_valu", 1, evals)}
+            "roofline": counter_roofline("trainable8", workload, "k_lds_minimize<8, false, false>", ms, "hbm", 1, evals)}
 
 
 def trainable12_aux(tq, B=512, maxfun=1000):
@@ -667,7 +668,7 @@ def trainable12_aux(tq, B=512, maxfun=1000):
     return {"workload": workload, "evals_per_s_per_gpu": evals / (ms * 1e-3), "env_steps_per_s_per_gpu": B / (ms * 1e-3),
             "mean_nfev": float(nfev.mean()), "kernel_ms": ms, "kernel": "k_lds_minimize<12, true, false>",
             "mean_energy": float(np.mean(f)),
-            "roofline": counter_roofline("trainable12", workload, "k_lds_minimize<12, true, false>", ms, "fp64_valu", 4, evals)}
+            "roofline": counter_roofline("trainable12", workload, "k_lds_minimize<12, true, false>", ms, "hbm", 4, evals)}
 
 
 def dm_aux(tq, n, ham, psi0, batch, G, n_circ=4):

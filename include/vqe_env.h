@@ -71,11 +71,14 @@ int vqe_vecenv_step_end(vqe_vecenv_t* v, int train_flag, float* reward, int32_t*
 /* per-environment attributes the drivers read (TensorRL_fixed_noiseless.py:136-143); each out[num_envs] */
 enum { VQE_ENV_ENERGY = 0, VQE_ENV_ERROR = 1, VQE_ENV_PREV_ENERGY = 2, VQE_ENV_NFEV = 3, VQE_ENV_DONE_THRESHOLD = 4,
        VQE_ENV_STEP_COUNTER = 5, VQE_ENV_REWARD = 6, VQE_ENV_N_GATES = 7, VQE_ENV_N_ROTATIONS = 8, VQE_ENV_LOWEST_ENERGY = 9,
-       VQE_ENV_EPISODES_COMPLETED = 10 };
+       VQE_ENV_EPISODES_COMPLETED = 10, VQE_ENV_HALTING_STEP = 11 /* -1: none */ };
 int vqe_vecenv_get(vqe_vecenv_t* v, int field, double* out);
 /* dense state tensor (num_layers, n+6, n) float32 of one environment, as CircuitEnv.state holds it */
 int vqe_vecenv_state(vqe_vecenv_t* v, int32_t env, float* dense);
 int vqe_vecenv_moments(vqe_vecenv_t* v, int32_t env, int32_t* moments /* n */, int32_t* slots /* n x 4, -1 = empty */);
+/* env.current_action / env.previous_action (environment_qulacs_TN_notin_agent.py:246,316): the [ctrl, offset, rot_qubit,
+ * rot_axis] of the last step and of the one before; either pointer may be NULL */
+int vqe_vecenv_actions(vqe_vecenv_t* v, int32_t env, int32_t* current /* 4 */, int32_t* previous /* 4 */);
 /* scipy's result.x of the last step (env.opt_ang_save): count via *n, values into out (may be NULL to query) */
 int vqe_vecenv_opt_ang(vqe_vecenv_t* v, int32_t env, double* out, int32_t* n);
 /* kernel time of the last launch (HIP events) */

@@ -98,6 +98,7 @@ SIGNATURES.update({
     "vqe_vecenv_get": (C.c_int, [vp, C.c_int, c_f64p]),
     "vqe_vecenv_state": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_float)]),
     "vqe_vecenv_moments": (C.c_int, [vp, C.c_int32, c_i32p, c_i32p]),
+    "vqe_vecenv_actions": (C.c_int, [vp, C.c_int32, c_i32p, c_i32p]),
     "vqe_vecenv_opt_ang": (C.c_int, [vp, C.c_int32, c_f64p, c_i32p]),
     "vqe_vecenv_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
 })

@@ -395,6 +395,7 @@ int vqe_vecenv_get(vqe_vecenv_t* v, int field, double* out) {
       case VQE_ENV_N_ROTATIONS: { int c = 0; for (auto& g : e.gates) c += g.kind != 0; val = c; break; }
       case VQE_ENV_LOWEST_ENERGY: val = e.lowest_energy; break;
       case VQE_ENV_EPISODES_COMPLETED: val = (double)e.episodes_completed; break;
+      case VQE_ENV_HALTING_STEP: val = (double)e.halting_step; break;
       default: return fail(v, VQE_EINVAL, "unknown field");
     }
     out[b] = val;
@@ -420,6 +421,14 @@ int vqe_vecenv_moments(vqe_vecenv_t* v, int32_t b, int32_t* moments, int32_t* sl
   const Env& e = v->env[b];
   if (moments) for (int i = 0; i < n; ++i) moments[i] = e.moments[i];
   if (slots) for (int i = 0; i < n; ++i) for (int k = 0; k < 4; ++k) slots[4 * i + k] = e.slot_used[i] ? e.slot[i].v[k] : -1;
+  return VQE_OK;
+}
+
+int vqe_vecenv_actions(vqe_vecenv_t* v, int32_t b, int32_t* current, int32_t* previous) {
+  if (!v || b < 0 || b >= v->cfg.num_envs) return VQE_EINVAL;
+  const Env& e = v->env[b];
+  if (current) std::memcpy(current, e.current.v, sizeof e.current.v);
+  if (previous) std::memcpy(previous, e.previous.v, sizeof e.previous.v);
   return VQE_OK;
 }
 

@@ -28,7 +28,17 @@ from ._core import CircuitEnvBase
 from .utils import curricula
 
 _FIELDS = {"energy": 0, "error": 1, "prev_energy": 2, "nfev": 3, "done_threshold": 4, "step_counter": 5, "rwd": 6,
-           "n_gates": 7, "n_rotations": 8, "lowest_energy": 9, "episodes_completed": 10}
+           "n_gates": 7, "n_rotations": 8, "lowest_energy": 9, "episodes_completed": 10, "halting_step": 11}
+# configuration attributes that really are the same for every environment of a batch (read from the prototype); any
+# OTHER name is per-environment state the native loop does not expose: an AttributeError, not environment 0's
+# construction-time value
+_SHARED = frozenset({
+    "TN_bond", "TN_init", "TN_state", "_action_index", "_actions_table", "_lmax", "action_size", "cnot_rwd_weight",
+    "curriculum_dict", "data_root", "depth_wise_gates", "device", "err_mitig", "fake_min_energy", "fn_type", "geometry",
+    "global_iters", "ham", "ham_mapping", "ham_model", "ham_type", "max_eig", "maxfev", "maxfevs", "min_eig", "n_shots",
+    "noise_flag", "noise_models", "noise_values", "noisy", "num_layers", "num_layers_termination", "num_qubits", "optim_alg",
+    "optim_method", "options", "phys_noise", "random_halt", "spec", "state_size", "state_with_angles", "tn_depth", "tn_gates",
+    "weights", "zero_param_init", "engine", "TRAINABLE", "NOISY"})
 
 
 class _EnvView:
@@ -41,7 +51,7 @@ class _EnvView:
         v, i = self._vec, self._i
         if name in _FIELDS:
             val = v._field(name)[i]
-            return int(val) if name in ("nfev", "step_counter", "n_gates", "n_rotations", "episodes_completed") else float(val)
+            return int(val) if name in ("nfev", "step_counter", "n_gates", "n_rotations", "episodes_completed", "halting_step") else float(val)
         if name == "state":
             return v.state_tensor(i)
         if name == "moments":
@@ -52,7 +62,13 @@ class _EnvView:
             return v.opt_ang(i)
         if name == "error_noiseless":
             return float(v._field("error")[i])
-        return getattr(v._proto, name)          # configuration attributes shared by all environments
+        if name in ("current_action", "action", "previous_action"):
+            cur, prev = v._actions(i)
+            return prev if name == "previous_action" else cur
+        if name in _SHARED:
+            return getattr(v._proto, name)      # configuration attributes shared by all environments
+        raise AttributeError(f"environment view of a native batch has no attribute {name!r} (per-environment state that "
+                             "the compiled host loop does not expose; use native=False for the Python objects)")
 
     def illegal_action_new(self):
         raise RuntimeError("native batch: use VecCircuitEnv.illegal_actions() (one call for all environments)")
@@ -151,6 +167,11 @@ class VecCircuitEnv:
         s = np.empty((n, 4), np.int32)
         self._chk(self._lib.vqe_vecenv_moments(self._h, int(i), m.ctypes.data_as(_lib.c_i32p), s.ctypes.data_as(_lib.c_i32p)))
         return [int(v) for v in m], [[int(v) for v in r] if r[0] >= 0 else [] for r in s]
+
+    def _actions(self, i):
+        cur, prev = np.zeros(4, np.int32), np.zeros(4, np.int32)
+        self._chk(self._lib.vqe_vecenv_actions(self._h, int(i), cur.ctypes.data_as(_lib.c_i32p), prev.ctypes.data_as(_lib.c_i32p)))
+        return [int(x) for x in cur], [int(x) for x in prev]
 
     def state_tensor(self, i):
         """Dense (L, n+6, n) float32 state tensor of environment ``i`` (what ``CircuitEnv.state`` holds)."""

@@ -232,6 +232,20 @@ def test_native_host_loop_equals_python_host_loop(data_root, cfg, module, steps)
             assert torch.equal(w.state, e.state)
             assert list(w.moments) == list(e.moments) and w.illegal_actions == [list(s) for s in e.illegal_actions]
             assert w.lowest_energy == e.curriculum.lowest_energy
+            # per-environment attributes come from the native handle, shared ones from the prototype, anything else raises
+            assert list(w.current_action) == list(e.current_action) == list(acts[b])
+            assert w.num_qubits == e.num_qubits and w.min_eig == e.min_eig and w.halting_step == -1
+            with pytest.raises(AttributeError):
+                w.save_circ
+        if t == 0:
+            # a bad action anywhere in the batch rejects the WHOLE call: no environment is advanced (review finding)
+            before = [(vn.envs[b].step_counter, list(vn.envs[b].moments), vn.envs[b].n_gates) for b in range(B)]
+            bad = [list(a) for a in acts]
+            bad[B - 1] = [0, 0, vn.num_qubits, 0]                 # CNOT with control == target
+            with pytest.raises(Exception):
+                vn.step(bad)
+            vn._cache.clear()
+            assert before == [(vn.envs[b].step_counter, list(vn.envs[b].moments), vn.envs[b].n_gates) for b in range(B)]
         if any(dn):
             idx = [b for b in range(B) if dn[b]]
             assert torch.equal(vn.reset(idx), vp.reset(idx))
