@@ -297,6 +297,15 @@ def heis20_aux(tq, torch, dist, rank, world, dev, steps):
     eng = tq.VQEEngine(n, dev)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_hamiltonian(ham.xmask, ham.zmask, ham.coeff)
+    # initial state: the package's own chi = 2-like init circuit for this chain (Lanczos ground state -> streaming MPS-to-PQC
+    # fit -> {rz, ry, cx} text, tools/make_heis20_init.py; |<gs|init>|^2 = 0.59, E = -33.56 against E0 = -36.01)
+    init_file = os.path.join(ROOT, "tensorrl-qas_amd", "data", "init_heisenberg_20q_TNbond2.qasm")
+    init_note = "|0...0>"
+    if os.path.exists(init_file):
+        ic, iang = tq.circuits.circuit_from_qasm_gates(tq.qasm.parse(open(init_file).read())[1])
+        eng.set_circuit(ic)
+        eng.set_init_state(eng.get_state(iang))
+        init_note = "tensorrl-qas_amd/data/init_heisenberg_20q_TNbond2.qasm (own fit of the Lanczos ground state)"
     eng.set_amplitude_shard(rank, world)     # every rank: all 77 terms on 1/world of the basis states
     batch = make_batch(tq, n, B, G, 2020)
     eng.batch_load_flat(batch["gate_off"], batch["kind"], batch["q0"], batch["q1"], batch["pidx"],
@@ -364,7 +373,7 @@ def heis20_aux(tq, torch, dist, rank, world, dev, steps):
                            "GBs_if_every_gate_and_group_streamed": bytes_per_eval * evals_s / 1e9,
                            "note": "SURVEY 8d figure 2^n*16*(2 G_rot + T_x): informational - the LDS-tiled kernels apply several "
                                    "ops / groups per pass over the state"}
-    return {"workload": "heisenberg_20q_77terms_G32_B256_sharded", "evals_per_s": evals_s,
+    return {"workload": "heisenberg_20q_77terms_G32_B256_sharded", "init_state": init_note, "evals_per_s": evals_s,
             "roofline": roof,
             "reduction_ms_per_batch": float(t[1].item()) / steps * 1e3,
             "reduction_evals_per_s": B * steps / float(t[1].item()),

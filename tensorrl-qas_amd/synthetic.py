@@ -112,7 +112,27 @@ def write_chain_dataset(root, n, model="heisenberg", seed=20, eigvals=None, init
     else:
         ham, _ = _ham.tfim(n, **kw)
         model = "tfim_j1_h0.05" if (kw.get("j", 1.0), kw.get("h")) == (1.0, 0.05) else ham.label.rsplit("_", 1)[0]
-    if init == "fit":
+    depth = 27
+    shipped = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"init_{model}_{n}q_TNbond2.qasm")
+    if init == "artefact" and not os.path.exists(shipped):
+        raise FileNotFoundError(f"{shipped}: no shipped init circuit for this model and size (tools/make_heis20_init.py)")
+    if init == "artefact":
+        # the init circuit this package's own chain produced (Lanczos ground state -> streaming fit -> {rz, ry, cx} text;
+        # tools/make_heis20_init.py, run once on a GPU box): what dmrg_to_qc.py:298-301 writes in the reference
+        import json
+        from . import qasm as _qasm
+        text = open(shipped).read()
+        meta = json.load(open(os.path.join(os.path.dirname(shipped), f"{model}_{n}q_meta.json")))
+        if eigvals is None:
+            eigvals = [meta["e0_lanczos"], float(3 * (n - 1) + n)]          # (upper bound of the chain: every term at +1)
+        nq, gates = _qasm.parse(text)
+        front = [0] * nq
+        for g in gates:                                   # ASAP depth, as the environments compute it
+            d = max(front[q] for q in g.qubits) + 1
+            for q in g.qubits:
+                front[q] = d
+        depth = max(front)
+    elif init == "fit":
         # the real thing instead of the stand-in: Lanczos ground state -> brickwork fit on the GPU -> QASM
         # (needs a GPU; ``fit_opts`` go to dmrg_to_qc.mps2qc.fit_state_to_init_circuit)
         from .dmrg_to_qc.mps2qc import fit_state_to_init_circuit
@@ -126,6 +146,6 @@ def write_chain_dataset(root, n, model="heisenberg", seed=20, eigvals=None, init
     with open(os.path.join(root, "init_state_circ", f"init_{model}_{n}q_TNbond2.qasm"), "w") as f:
         f.write(text)
     conf = copy.deepcopy(HEIS_FIXED_CONFIG_TEMPLATE)
-    conf["env"].update(num_qubits=n, num_layers=27 + 40, data_root=root)
+    conf["env"].update(num_qubits=n, num_layers=depth + 40, data_root=root)
     conf["problem"]["ham_type"] = model
     return conf
