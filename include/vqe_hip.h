@@ -106,6 +106,15 @@ int vqe_set_term_shard(vqe_t* h, int rank, int world);
  * partial energies are summed by the caller exactly as for term sharding.  Work and memory
  * traffic of the reduction are 1/world per rank. */
 int vqe_set_amplitude_shard(vqe_t* h, int rank, int world);
+/* The one collective of the term-sharded sum as a library call (RCCL over xGMI; librccl is opened lazily).  Rank 0
+ * makes the 128-byte id (vqe_comm_unique_id) and hands it to the other ranks by any means; every rank calls
+ * vqe_comm_init on its handle; vqe_comm_allreduce_energy sums the batch's energy array (float64[batch], what
+ * vqe_batch_run_energy left on the device and vqe_batch_fetch returns) over the ranks, in place, asynchronously on
+ * the handle's stream.  The reference has no counterpart (single process). */
+int vqe_comm_unique_id(void* id128);
+int vqe_comm_init(vqe_t* h, int rank, int world, const void* id128);
+int vqe_comm_allreduce_energy(vqe_t* h);
+int vqe_comm_destroy(vqe_t* h);
 /* host only: the rank that vqe_set_term_shard(.., world) makes responsible for each term
  * (terms sharing an X mask stay together); needs no device */
 int vqe_term_owner(int n_qubits, int n_terms, const uint64_t* xmask, int world, int32_t* owner);

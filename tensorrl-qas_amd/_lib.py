@@ -38,6 +38,10 @@ SIGNATURES = {
     "vqe_set_hamiltonian_dense": (C.c_int, [vp, c_f64p, C.c_double]),
     "vqe_hamiltonian_terms": (C.c_int, [vp, c_i32p, c_i32p]),
     "vqe_hamiltonian_layout": (C.c_int, [vp, c_i32p]),
+    "vqe_comm_unique_id": (C.c_int, [vp]),
+    "vqe_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "vqe_comm_allreduce_energy": (C.c_int, [vp]),
+    "vqe_comm_destroy": (C.c_int, [vp]),
     "vqe_set_noise_mode": (C.c_int, [vp, C.c_int]),
     "vqe_noise_mode_info": (C.c_int, [vp, c_i32p]),
     "vqe_set_init_state_dev": (C.c_int, [vp, vp]),

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <new>
 #include <string>
@@ -110,6 +111,8 @@ struct vqe_handle {
   uint64_t dm_ham_gen = ~0ull;
   DevBuf<double> d_cob_x0, d_cob_xres, d_cob_f;      // device-resident lock-step COBYLA of the streaming path
   DevBuf<int32_t> d_cob_nfev, d_cob_active;
+  void* comm = nullptr;      // RCCL communicator of vqe_comm_init (ncclComm_t)
+  int comm_world = 0;
   StreamWork sw;  // streaming-path work buffers
   uint64_t gen = 0;   // bumped whenever a resident batch / Hamiltonian shard / noise setting changes (plans of vqe_tile.h)
 };
@@ -1316,6 +1319,7 @@ void vqe_destroy(vqe_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->dev);
   (void)hipStreamSynchronize(h->stream);
+  if (h->comm) (void)vqe_comm_destroy(h);
   if (h->dm_ev0) (void)hipEventDestroy(h->dm_ev0);
   if (h->dm_ev1) (void)hipEventDestroy(h->dm_ev1);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1468,6 +1472,86 @@ int vqe_hamiltonian_terms(vqe_t* h, int32_t* n_terms, int32_t* n_xgroups) {
   if (!h->ham_set) return fail(h, VQE_ESTATE, "no Hamiltonian set");
   *n_terms = (int32_t)h->hx.size();
   *n_xgroups = (int32_t)h->gx_all.size();
+  return VQE_OK;
+}
+
+// ---- RCCL behind the C ABI ----------------------------------------------------------------------------------------
+// The collective of the term-sharded expectation sum as a library call: one ncclAllReduce(SUM, float64, count = batch) of
+// the handle's energy array, in place, on the handle's stream.  librccl is opened lazily (no link-time dependency: a
+// process that never shards never loads it; under PyTorch the already-loaded copy of the same SONAME is reused).
+namespace {
+struct Id128 { char b[128]; };      // ncclUniqueId, passed by value
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+Rccl& rccl() {
+  static Rccl r;
+  if (!r.lib) {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (r.lib) {
+      r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+      r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+      r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+      r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+      r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+      r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy;
+    }
+  }
+  return r;
+}
+}  // namespace
+
+int vqe_comm_unique_id(void* id128) {
+  if (!id128) return VQE_EINVAL;
+  Rccl& r = rccl();
+  if (!r.ok) return fail(nullptr, VQE_ENODEV, "librccl not found");
+  const int rc = r.GetUniqueId(id128);
+  return rc ? fail(nullptr, VQE_EHIP, std::string("ncclGetUniqueId: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error")) : VQE_OK;
+}
+
+int vqe_comm_init(vqe_t* h, int rank, int world, const void* id128) {
+  if (!h || !id128) return VQE_EINVAL;
+  if (world < 1 || rank < 0 || rank >= world) return fail(h, VQE_EINVAL, "bad rank / world");
+  if (h->comm) return fail(h, VQE_ESTATE, "communicator exists already (vqe_comm_destroy first)");
+  Rccl& r = rccl();
+  if (!r.ok) return fail(h, VQE_ENODEV, "librccl not found");
+  HIP_TRY(h, hipSetDevice(h->dev));
+  Id128 id;
+  std::memcpy(id.b, id128, 128);
+  void* comm = nullptr;
+  const int rc = r.CommInitRank(&comm, world, id, rank);
+  if (rc) return fail(h, VQE_EHIP, std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error"));
+  h->comm = comm;
+  h->comm_world = world;
+  return VQE_OK;
+}
+
+int vqe_comm_allreduce_energy(vqe_t* h) {
+  if (!h) return VQE_EINVAL;
+  if (!h->comm) return fail(h, VQE_ESTATE, "vqe_comm_init has not been called");
+  if (h->batch <= 0) return fail(h, VQE_ESTATE, "no batch loaded");
+  Rccl& r = rccl();
+  const int rc = r.AllReduce(h->d_f.p, h->d_f.p, (size_t)h->batch, /* ncclFloat64 */ 8, /* ncclSum */ 0, h->comm, h->stream);
+  return rc ? fail(h, VQE_EHIP, std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error")) : VQE_OK;
+}
+
+int vqe_comm_destroy(vqe_t* h) {
+  if (!h) return VQE_EINVAL;
+  if (h->comm) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)rccl().CommDestroy(h->comm);
+    h->comm = nullptr;
+    h->comm_world = 0;
+  }
   return VQE_OK;
 }
 

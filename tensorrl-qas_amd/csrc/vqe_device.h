@@ -1366,14 +1366,15 @@ __device__ __forceinline__ double reg_energy(const Lds& L, const HamDev& H, Hook
 }
 
 // One evaluation with the ops already compiled: circuit, then <psi|H|psi>.
+// cs_ready: the (cos, sin) of the angles are in L.cs already (StagedCobyla::out formed them from the trial point)
 template <int N, bool SLOTS = false, class Hook = NoHook>
 __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L, const double* theta, int P,
-                                               int p_hole = -1, Hook after_pairs = Hook()) {
+                                               int p_hole = -1, Hook after_pairs = Hook(), bool cs_ready = false) {
 #ifdef VQE_STAMPS
   const long long t0 = clock64();
 #endif
   if constexpr (N >= kRegMinQubits) {
-    run_ops_reg<N, SLOTS>(L, A.init, theta, P, p_hole, A.dbg);
+    run_ops_reg<N, SLOTS>(L, A.init, theta, P, p_hole, A.dbg, cs_ready);
   } else {
     load_init<N>(L, A.init);
     __syncthreads();
@@ -1399,6 +1400,21 @@ __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L,
 typedef __attribute__((address_space(3))) double lds_double;
 struct NoSide { __device__ __forceinline__ void operator()() const {} };
 
+// K double2 values that stay in registers: members of a recursive struct are scalars from the start (a plain member
+// array that is indexed inside loops and lambdas is left in scratch memory by the compiler)
+template <int K>
+struct KeepRegs {
+  double2 v;
+  KeepRegs<K - 1> rest;
+  template <class F> __device__ __forceinline__ void load(F f, int k = 0) { v = f(k); rest.load(f, k + 1); }
+  template <class F> __device__ __forceinline__ void store(F f, int k = 0) const { f(k, v); rest.store(f, k + 1); }
+};
+template <>
+struct KeepRegs<0> {
+  template <class F> __device__ __forceinline__ void load(F, int = 0) {}
+  template <class F> __device__ __forceinline__ void store(F, int = 0) const {}
+};
+
 // WIDE: compile the workgroup-wide update in (always for n >= 10; below that only in the kernel variant that is
 // launched for batches with more than 64 parameters - the trainable regime - because its registers cost the
 // 128-VGPR kernels 10-20 % at small parameter counts)
@@ -1417,7 +1433,20 @@ struct StagedCobyla {
   bool staged;
   bool resident;   // the arrays live in an LDS region of their own (Lds::cob): nothing is copied
   int want, nfvals;   // published after start()/tell()
+  // PRE: the first kStage double2 per thread of the staging copy are requested from L2 while the energy step still
+  // runs (prefetch(), called from reg_energy once its class loop has released its registers) and written to LDS by
+  // in(): the 2.7 k cycles of L2 latency that in() used to wait for are gone (round 3; n >= 10 only)
+#ifndef VQE_STAGE_PREFETCH
+#define VQE_STAGE_PREFETCH 1
+#endif
+#ifndef VQE_LIGHT_OUT
+#define VQE_LIGHT_OUT 0      // measured (12 qubits, bench workload): prefetch alone 322.9 ms, light barrier alone 329.6, both 329.2, neither 324.5
+#endif
+  static constexpr bool PRE = VQE_STAGE_PREFETCH && N >= 10 && Geo<N>::NT >= 256;
+  KeepRegs<PRE ? 6 : 0> pre;
+  bool pre_valid;
   __device__ __forceinline__ void init(double* global_scratch, const Lds& L, int n_) {
+    pre_valid = false;
     gmem = global_scratch;
     resident = L.cob != nullptr;
     lmem = resident ? L.cob : (double*)L.psi;
@@ -1436,12 +1465,35 @@ struct StagedCobyla {
   // waits for every load in turn: ~5 dependent L2 round trips per call), in chunks of kStage
   // double2 per thread.
   static constexpr int kStage = 6;
+  __device__ __forceinline__ void prefetch() {
+    if constexpr (PRE) {
+      if (!staged || resident) return;
+      const double2* s = (const double2*)gmem;
+      const int nw = (words + 1) / 2;
+      pre.load([&](int k) {
+        const int i = (int)threadIdx.x + k * kThreads;
+        return s[i < nw ? i : nw - 1];
+      });
+      pre_valid = true;
+    }
+  }
   __device__ __forceinline__ void in() {
     if (!staged || resident) return;
     const double2* s = (const double2*)gmem;
     double2* d = (double2*)lmem;
     const int nw = (words + 1) / 2;
-    for (int i0 = threadIdx.x; i0 < nw; i0 += kStage * kThreads) {
+    int first = threadIdx.x;
+    if constexpr (PRE) {
+      if (pre_valid) {      // chunk 0 is in registers already
+        pre.store([&](int k, const double2& v) {
+          const int i = (int)threadIdx.x + k * kThreads;
+          if (i < nw) d[i] = v;
+        });
+        pre_valid = false;
+        first += kStage * kThreads;
+      }
+    }
+    for (int i0 = first; i0 < nw; i0 += kStage * kThreads) {
       double2 v[kStage];
 #pragma unroll
       for (int k = 0; k < kStage; ++k) {
@@ -1460,11 +1512,25 @@ struct StagedCobyla {
     }
     __syncthreads();
   }
-  __device__ __forceinline__ void out() {
+  // cs_out != nullptr (and the optimiser wants another evaluation): the (cos, sin)(x/2) of the trial point are formed
+  // HERE from the LDS copy of x (parameter j of the circuit at cs_out[j]; p_hole: the parameter that is not a
+  // variable), so the coming evaluation reads nothing that out() writes to global memory and the closing barrier need
+  // not wait for the write-back to be acknowledged (LDS-only barrier: 2.5 k cycles of every tell()).  `full`: the caller
+  // reads x / the scalars from the scratch next (finish, trace): the ordinary barrier.
+  __device__ __forceinline__ bool out(bool full = true, double2* cs_out = nullptr, int P = 0, int p_hole = -1) {
     if (threadIdx.x == 0) { pub[0] = want; pub[1] = nfvals; }
     __syncthreads();
     want = pub[0]; nfvals = pub[1];
-    if (!staged || resident) return;
+    if (!staged || resident) return false;
+    const bool light = VQE_LIGHT_OUT && !full && want && cs_out != nullptr;
+    if (light) {
+      for (int j = threadIdx.x; j < P; j += kThreads) {
+        if (j == p_hole) continue;
+        double sn, cn;
+        sincos(0.5 * lmem[j - (p_hole >= 0 && j > p_hole)], &sn, &cn);
+        cs_out[j] = make_double2(cn, sn);
+      }
+    }
     const double2* s = (const double2*)lmem;
     double2* d = (double2*)gmem;
     const int nw = (words + 1) / 2;
@@ -1488,7 +1554,12 @@ struct StagedCobyla {
     // every thread has its part of the staging area in registers by now (the stores above waited for
     // the LDS reads), and whatever overwrites the state region next - the first re-layout or the
     // final scatter of the coming evaluation, the x[] copy of the result - sits behind a barrier
+    if (light) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS reads done; the global stores drain on their own
+      return true;
+    }
     __syncthreads();
+    return false;
   }
   // FIRST: start() instead of tell().  The optimiser object lives only inside this call.
   template <bool FIRST, class Cob, class Ptr>
@@ -1516,8 +1587,10 @@ struct StagedCobyla {
   }
   // `side()` runs on the second wave while the first one does the optimiser's bookkeeping (the
   // env-step kernel prepares the noise patches of the next evaluation there)
+  bool cs_ready;      // out() formed the (cos, sin) of the coming evaluation
   template <bool FIRST, class Side>
-  __device__ __forceinline__ int run(double f, double rhobeg, double rhoend, int maxfun, Side side) {
+  __device__ __forceinline__ int run(double f, double rhobeg, double rhoend, int maxfun, Side side, bool full = true,
+                                     double2* cs_out = nullptr, int P = 0, int p_hole = -1) {
 #ifdef VQE_STAMPS
     const long long t0 = clock64();
 #endif
@@ -1546,7 +1619,7 @@ struct StagedCobyla {
 #ifdef VQE_STAMPS
     const long long t2 = clock64();
 #endif
-    out();
+    cs_ready = out(full, cs_out, P, p_hole);
 #ifdef VQE_STAMPS
     if (threadIdx.x == 0 && !FIRST) {
       atomicAdd(&g_cby_dbg[7], (unsigned long long)(t2 - t1));          // wave 0: load_state + tell + save_state
@@ -1556,13 +1629,17 @@ struct StagedCobyla {
 #endif
     return want;
   }
-  __device__ __forceinline__ int start(double rhobeg, double rhoend, int maxfun) { return run<true>(0.0, rhobeg, rhoend, maxfun, NoSide()); }
+  __device__ __forceinline__ int start(double rhobeg, double rhoend, int maxfun, bool full = true, double2* cs_out = nullptr,
+                                       int P = 0, int p_hole = -1) {
+    return run<true>(0.0, rhobeg, rhoend, maxfun, NoSide(), full, cs_out, P, p_hole);
+  }
   template <class Side>
-  __device__ __forceinline__ int tell(double f, unsigned long long* __restrict__ dbg, Side side) {
+  __device__ __forceinline__ int tell(double f, unsigned long long* __restrict__ dbg, Side side, bool full = true,
+                                      double2* cs_out = nullptr, int P = 0, int p_hole = -1) {
 #ifdef VQE_STAMPS
     const long long t0 = clock64();
 #endif
-    const int w = run<false>(f, 0.0, 0.0, 0, side);
+    const int w = run<false>(f, 0.0, 0.0, 0, side, full, cs_out, P, p_hole);
 #ifdef VQE_STAMPS
     if (threadIdx.x == 0) atomicAdd(dbg + 4, (unsigned long long)(clock64() - t0));
 #endif
@@ -1649,6 +1726,10 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
   stage_groups(A.ham, L);
   if constexpr (N >= 10) stage_cls<N>(A.ham, L);
   StagedCobyla<N, WIDE> sc;
+  sc.cs_ready = false;
+  // the write-back of the optimiser's arrays must be visible to the rest of the workgroup only when somebody reads it
+  // from the scratch: the trace does (the result path asks for it itself)
+  const bool full_out = N < 10 || A.trace != nullptr;
   // phases: 0 = single evaluation (empty x0: scipy returns after one call), 1 = COBYLA loop,
   // 2 = post-action evaluation of env_step.  ONE evaluation call site keeps everything inlined.
   int phase = 0, nfev = 1;
@@ -1660,7 +1741,7 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
     for (int j = threadIdx.x; j < P; j += kThreads)
       if (j != p_hole) sc.x()[j - (p_hole >= 0 && j > p_hole)] = theta[j];
     __syncthreads();
-    sc.start(A.rhobeg, A.rhoend, A.maxfun);   // always asks for f(x0)
+    sc.start(A.rhobeg, A.rhoend, A.maxfun, full_out, L.cs, P, p_hole);   // always asks for f(x0)
     phase = 1;
   }
   for (;;) {
@@ -1673,7 +1754,8 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
     if (need_compile) { compile_all<N>(A, b, 0, L, sk, true, noisy, ske); need_compile = false; patched = false; }
     if (noisy && !patched) patch_noise<N>(A, b, eid, L, sk, true, ske);
     patched = false;
-    double e = lds_evaluate<N, NOISY>(A, L, th, P, ph);
+    const bool csr = phase == 1 && sc.cs_ready;
+    double e = lds_evaluate<N, NOISY>(A, L, th, P, ph, [&]() { if (phase == 1) sc.prefetch(); }, csr);
     // finite-shot estimate of <H>: Gaussian with the total standard deviation the caller set
     if (A.noise.shot_sigma != 0.0) e += A.noise.shot_sigma * noise_gauss(A.noise.seed, (uint64_t)b, eid);
     bool finished_opt = false;
@@ -1698,7 +1780,7 @@ __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchA
       const uint64_t eid_next = A.noise.eval_base + (uint64_t)sc.nfvals + 1;
       const int want = sc.tell(e, A.dbg, [&]() {
         if (noisy) patch_noise_wave<N>(A, b, eid_next, L, sk, true, (int)(threadIdx.x & 63), ske);
-      });
+      }, full_out, L.cs, P, p_hole);
       patched = noisy && want;
 #ifdef VQE_STAMPS
       if (threadIdx.x == 0) atomicAdd(A.dbg + 3, (unsigned long long)(clock64() - tt0));

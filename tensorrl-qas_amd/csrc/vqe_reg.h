@@ -224,7 +224,7 @@ __device__ __forceinline__ void ry_pairs(double2 (&amp)[NA], double c, double s,
 // LOGICAL order (same contract as run_ops).
 template <int N, bool SLOTS = false>
 __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restrict__ init, const double* theta, int P,
-                                   int p_hole = -1, unsigned long long* __restrict__ dbg = nullptr) {
+                                   int p_hole = -1, unsigned long long* __restrict__ dbg = nullptr, bool cs_ready = false) {
 #ifdef VQE_STAMPS
   const long long ts0 = clock64();
   long long trel = 0;
@@ -235,11 +235,13 @@ __device__ __forceinline__ void run_ops_reg(const Lds& L, const double2* __restr
   constexpr int NA = 1 << R;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));   // opaque (see reg_energy)
-  for (int j = tid; j < P; j += kThreads) {
-    if (j == p_hole) continue;
-    double s, c;
-    sincos(0.5 * theta[j - (p_hole >= 0 && j > p_hole)], &s, &c);
-    L.cs[j] = make_double2(c, s);
+  if (!cs_ready) {      // (else: formed by StagedCobyla::out from the trial point while it was in LDS)
+    for (int j = tid; j < P; j += kThreads) {
+      if (j == p_hole) continue;
+      double s, c;
+      sincos(0.5 * theta[j - (p_hole >= 0 && j > p_hole)], &s, &c);
+      L.cs[j] = make_double2(c, s);
+    }
   }
   double2 amp[NA];
   // layout vectors and the thread's base index are kept as BYTE offsets (<< 4): one XOR per

@@ -146,6 +146,25 @@ class VQEEngine:
         self._chk(self._lib.vqe_hamiltonian_layout(self._h, out))
         return {"table_groups": out[0], "units": out[1], "class_groups": out[2], "has_diag": bool(out[3])}
 
+    # -- RCCL behind the C ABI (the collective of the term-sharded sum as a library call) -----------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = _lib.load().vqe_comm_unique_id(buf)
+        if rc:
+            raise VQEError(f"vqe_comm_unique_id failed ({rc})")
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self._lib.vqe_comm_init(self._h, int(rank), int(world), buf))
+
+    def comm_allreduce_energy(self):
+        self._chk(self._lib.vqe_comm_allreduce_energy(self._h))
+
+    def comm_destroy(self):
+        self._chk(self._lib.vqe_comm_destroy(self._h))
+
     def set_term_shard(self, rank: int, world: int):
         self._chk(self._lib.vqe_set_term_shard(self._h, int(rank), int(world)))
 

@@ -824,3 +824,31 @@ def test_dense_hamiltonian_entry_point(tq):
         e4.set_hamiltonian_dense(dn + 0.3j * np.eye(16))
     with pytest.raises(ValueError):
         tq.VQEEngine(14).set_hamiltonian_dense(np.zeros((1, 1)))    # wrong shape is caught by the wrapper
+
+
+def test_rccl_allreduce_behind_the_c_abi_world_1(tq):
+    """vqe_comm_unique_id / vqe_comm_init / vqe_comm_allreduce_energy: the collective of the term-sharded sum as a library
+    call.  One GPU on the test box, so the communicator has ONE rank: the call chain (lazy dlopen of librccl,
+    ncclCommInitRank, ncclAllReduce on the handle's stream, ncclCommDestroy) executes and leaves the energies unchanged."""
+    n = 10
+    rng = np.random.default_rng(77)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 20, rng)
+    kind, q0, q1, pidx, th = random_gates(n, 12, rng)
+    eng = _engine(tq, n, psi0, ham)
+    circ = tq.Circuit(kind, q0, q1, pidx, th.size)
+    eng.batch_load([circ, circ], [th, th + 0.1])
+    eng.batch_run_energy()
+    ref = eng.batch_fetch(want_x=False)[1].copy()
+    uid = tq.VQEEngine.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.comm_init(0, 1, uid)
+    with pytest.raises(tq.VQEError):
+        eng.comm_init(0, 1, uid)                       # one communicator per handle
+    eng.comm_allreduce_energy()
+    got = eng.batch_fetch(want_x=False)[1]
+    assert np.array_equal(got, ref)
+    assert abs(got[0] - vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th), *ham)) < E_TOL
+    eng.comm_destroy()
+    with pytest.raises(tq.VQEError):
+        eng.comm_allreduce_energy()
