@@ -101,16 +101,23 @@ constexpr int kStateDoubles = 15;
 // Leading dimension of sim / simi: odd, so that walking a matrix along either index touches
 // distinct LDS banks (a stride of n doubles with n = 32 puts a whole column in one bank).
 CBY_HD int lead_dim(int nv) { return nv | 1; }
+// ... and for device arrays in GLOBAL memory a multiple of 8 doubles: every row then starts on a 64-byte boundary and
+// a batch of 8 consecutive elements of a row is ONE 64-byte sector (with the odd stride of the LDS layout every batch
+// straddled two: twice the L2 / HBM traffic of the row loops, which is what bounds the trainable regime).
+CBY_HD int lead_dim_global(int nv) { return (nv + 7) & ~7; }
 
 // Parallel contexts run the inner (serial) loops of a row to nv = n rounded up to kPad, in
 // batches of kPad with every load of a batch in flight together; the padding entries are
 // zero and stay zero, dummy vertices n..nv-1 sit between the real ones and the pole (index nv).
 CBY_HD int padded(int n, int pad) { return (n + pad - 1) / pad * pad; }
 
-CBY_HD size_t scratch_doubles(int n, int pad = 8) {
+CBY_HD size_t scratch_doubles_ld(int n, int pad, int ld_) {
   // x, sim, simi, datmat, a, vsig, veta, sigbar, dx, w, tdot, state
-  const size_t nv = (size_t)padded(n, pad), ld = (size_t)lead_dim((int)nv);
+  const size_t nv = (size_t)padded(n, pad), ld = (size_t)ld_;
   return nv + (nv + 1) * ld + nv * ld + (nv + 1) + 7 * nv + 2 + kStateDoubles;
+}
+CBY_HD size_t scratch_doubles(int n, int pad = 8) {      // (odd leading dimension: an upper bound for the global layout too)
+  return scratch_doubles_ld(n, pad, lead_dim(padded(n, pad)));
 }
 
 // Real is `double`, or an address-space qualified double (LDS) on the device so that the
@@ -138,6 +145,8 @@ struct CobylaM0 {
   // (only where the arrays live in global memory - plain `double` - : with LDS-resident arrays the sweep is cheap and
   // the extra branch costs the fused 12-qubit kernel 0.8 %)
   static constexpr bool kIncrementalEta = std::is_same<Real, double>::value;
+  // device contexts on arrays in global memory: rows on 64-byte boundaries (lead_dim_global)
+  static constexpr bool kGlobalRows = std::is_same<Real, double>::value && (Ctx::nth == 64);
 
   CBY_HD Real &SIM(int i, int j) { return sim[(size_t)j * ld + i]; }    // coordinate i of vertex j
   CBY_HD Real &SIMI(int j, int i) { return simi[(size_t)j * ld + i]; }  // row j of the inverse
@@ -145,7 +154,7 @@ struct CobylaM0 {
   CBY_HD void bind(Real *mem, int n_) {
     n = n_;
     nv = padded(n, Ctx::kPad);
-    ld = lead_dim(nv);
+    ld = kGlobalRows ? lead_dim_global(nv) : lead_dim(nv);
     x = mem; mem += nv;
     sim = mem; mem += (size_t)(nv + 1) * ld;
     simi = mem; mem += (size_t)nv * ld;

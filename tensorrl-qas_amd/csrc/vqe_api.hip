@@ -729,7 +729,7 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   for (int b = 0; b < batch; ++b) {
     sbeg[b] = stot;
     stot += (int64_t)cby::scratch_doubles(pcnt[b], 16);   // the larger of the device contexts' paddings
-    stot = (stot + 1) & ~(int64_t)1;  // keep 16-byte alignment
+    stot = (stot + 7) & ~(int64_t)7;  // 64-byte alignment: rows of the optimiser's global arrays are whole sectors
     max_par = std::max(max_par, (int)pcnt[b]);
     int ops = 0;
     for (int64_t i = gbeg[b]; i < gbeg[b] + gcnt[b]; ++i) {
