@@ -628,9 +628,9 @@ int check_gates(vqe_t* h, int64_t n_gates, const int32_t* kind, const int32_t* q
 template <int N>
 int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
   size_t lds = lds_bytes(N, A.max_ops, A.max_params, A.ham.n_groups);
-#ifdef VQE_STAMPS   // diagnostic build: VQE_LDS_PAD=bytes lowers the workgroups per CU
-  if (const char* pad = std::getenv("VQE_LDS_PAD")) lds += (size_t)std::atol(pad);
-#endif
+  // measurement knob: VQE_LDS_PAD=bytes of unused LDS per workgroup lowers the workgroups per CU
+  static const long lds_pad = [] { const char* e = std::getenv("VQE_LDS_PAD"); return e ? std::atol(e) : 0L; }();
+  if (lds_pad > 0) lds += (size_t)lds_pad;
   if (lds > (size_t)h->lds_per_cu)
     return fail(h, VQE_EINVAL, "circuit too large for the LDS-resident path (gates + parameters)");
   // register path: the raw ops are staged in the (idle) state region, 2^n records at most
@@ -1041,34 +1041,52 @@ void sup_depol(int mask, double p, Sup& S) {
 
 struct DmBlockHost { int a, b; Sup S; };
 
-// Gate list -> superoperator blocks: a block collects every consecutive gate / channel that stays inside its
-// two-qubit window.  Gate semantics as in vqe_device.h (qulacs: R = exp(+i theta/2 P), CNOT(control, target)).
+// Gate list -> superoperator blocks.  A block collects the gates / channels that stay inside its two-qubit window; blocks
+// on DISJOINT windows commute (they act on different index bits of rho), so several blocks are open at a time and a
+// gate joins the open block that holds all of its qubits wherever that block was opened; a gate that touches an open
+// window without fitting into it closes that block first (blocks are emitted in the order they are closed, which keeps
+// every qubit's own sequence of operations intact).  Gate semantics as in vqe_device.h (qulacs: R = exp(+i theta/2 P),
+// CNOT(control, target)).  Bench circuits (63 gates + 63 channels on 12 qubits): 57 blocks with consecutive fusion
+// only, ~40 with this one.
 void dm_make_blocks(int n, const GateRec* g, int G, const double* theta, double p1, double p2, std::vector<DmBlockHost>& out) {
   out.clear();
-  int wa = -1, wb = -1;
-  DmBlockHost cur{};
-  auto flush = [&]() { if (wa >= 0) out.push_back(cur); wa = wb = -1; };
+  std::vector<DmBlockHost> open;            // pairwise disjoint windows
+  auto owner = [&](int q) { for (size_t k = 0; k < open.size(); ++k) if (open[k].a == q || open[k].b == q) return (int)k; return -1; };
+  auto close = [&](int k) { out.push_back(open[k]); open.erase(open.begin() + k); };
   for (int i = 0; i < G; ++i) {
     const GateRec r = g[i];
     const bool two = r.kind == G_CNOT || r.kind == G_DEPOL2;
     const int qa = r.q0, qb = two ? r.q1 : -1;
-    const bool fits = wa >= 0 && (qa == wa || qa == wb) && (!two || qb == wa || qb == wb);
-    if (!fits) {
-      flush();
-      wa = qa;
-      wb = qb;
-      if (wb < 0) {      // a one-qubit gate opens the window: its partner is the other qubit of the next gate that touches it
-        for (int k = i + 1; k < G && wb < 0; ++k) {
-          const bool t2 = g[k].kind == G_CNOT || g[k].kind == G_DEPOL2;
-          if (t2 && g[k].q0 == qa) wb = g[k].q1;
-          else if (t2 && g[k].q1 == qa) wb = g[k].q0;
-          else if (t2) break;
+    int k = owner(qa);
+    const int k2 = two ? owner(qb) : k;
+    if (k < 0 || k2 != k) {
+      // no open block holds all qubits of the gate: close the ones it touches (the higher index first), open a new one
+      const int c1 = k, c2 = two ? k2 : -1;
+      if (c1 >= 0 && c2 >= 0 && c1 != c2) { close(std::max(c1, c2)); close(std::min(c1, c2)); }
+      else if (c1 >= 0) close(c1);
+      else if (c2 >= 0) close(c2);
+      DmBlockHost nb{};
+      nb.a = qa;
+      nb.b = qb;
+      if (nb.b < 0) {
+        // a one-qubit gate opens the window: its partner is the other qubit of the next two-qubit gate that touches it,
+        // if that qubit is free; else any free qubit; if every other qubit sits in an open window, the oldest block goes
+        int want = -1;
+        for (int j = i + 1; j < G && want < 0; ++j) {
+          const bool t2 = g[j].kind == G_CNOT || g[j].kind == G_DEPOL2;
+          if (t2 && g[j].q0 == qa) want = g[j].q1;
+          else if (t2 && g[j].q1 == qa) want = g[j].q0;
         }
-        if (wb < 0) wb = (qa + 1) % n;
+        if (want >= 0 && owner(want) < 0) nb.b = want;
+        for (int q = 0; q < n && nb.b < 0; ++q) if (q != qa && owner(q) < 0) nb.b = q;
+        if (nb.b < 0) { nb.b = open[0].a; close(0); }
       }
-      cur.a = wa; cur.b = wb;
-      sup_identity(cur.S);
+      sup_identity(nb.S);
+      open.push_back(nb);
+      k = (int)open.size() - 1;
     }
+    DmBlockHost& cur = open[k];
+    const int wa = cur.a;
     Sup Gs;
     if (r.kind == G_CNOT) {
       const int pc = r.q0 == wa ? 0 : 1, pt = pc ^ 1;
@@ -1090,7 +1108,7 @@ void dm_make_blocks(int n, const GateRec* g, int G, const double* theta, double 
     }
     sup_apply(cur.S, Gs);
   }
-  flush();
+  while (!open.empty()) close(0);
 }
 
 // this handle's Hamiltonian terms (all of its share under term sharding) for k_dm_energy
