@@ -482,12 +482,23 @@ int build_hamiltonian(vqe_t* h) {
     }
     if (utab.size() * sizeof(double) + (size_t)kUnitUnroll * NT * sizeof(double) > 0x7FFFFFFFu)
       return fail(h, VQE_EINVAL, "Hamiltonian too large for the LDS-resident path");
-    // padding to a multiple of kUnitUnroll: units with a table of zeros (unit k owns table doubles [k NT, (k+1) NT):
-    // the kernel derives the offset from the unit index)
+    // padding to a multiple of kUnitUnroll: units with a table of zeros
     while ((urec.size() / 8) % kUnitUnroll) {
       const uint32_t rec[8] = {0, 0, 0, 0, 0, 0, 0, (uint32_t)(utab.size() * sizeof(double))};
       urec.insert(urec.end(), rec, rec + 8);
       utab.resize(utab.size() + NT, 0.0);
+    }
+    // table layout the unit loop reads: per trip of kUnitTrip units [thread][unit of the trip] - a thread's values of a
+    // trip are 32 contiguous bytes (two 16-byte loads instead of four 8-byte ones, one offset computation per trip:
+    // 335.7 -> 331.2 ms on one box)
+    {
+      std::vector<double> t(utab.size());
+      const size_t n_trips = urec.size() / 8 / kUnitTrip;
+      for (size_t T = 0; T < n_trips; ++T)
+        for (size_t j = 0; j < (size_t)kUnitTrip; ++j)
+          for (size_t th = 0; th < NT; ++th)
+            t[(T * NT + th) * kUnitTrip + j] = utab[(T * kUnitTrip + j) * NT + th];
+      utab.swap(t);
     }
   }
   auto gxm = [&](int g) { return im.map_x(h->gx_all[g]); };

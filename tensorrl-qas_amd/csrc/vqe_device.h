@@ -1125,6 +1125,9 @@ __device__ __forceinline__ void pair_fma1(double& acc0, const double2& a0, const
 // the fixed bits, the X mask and the offset of the unit's NT table values.  No dispatch of any kind: 7 integer
 // instructions, 2 ds_read_b128, one 8-byte table load and 3 FP64 instructions per unit and thread, against ~60
 // instructions, 8 ds_read_b128 and 64 table bytes for a group of the class path below.
+// (Measured and dropped: trips whose four units share ONE deposit - a hopping pair's four units differ in two filler
+// bits only -: 13 instead of 28 integer instructions for 28 of the bench Hamiltonian's 45 trips, but a second loop, its
+// own prologue and padding of both phases to whole turns: 326.4 ms against 327.8, not worth a second code path.)
 // LDS read at an ABSOLUTE byte address.  The state region starts the dynamic LDS of these kernels and they have no
 // static LDS (launch_lds checks the function's static size), so its address is 0; going through the `smem` symbol
 // costs a v_add_u32 of that late-bound zero per read.
@@ -1146,7 +1149,9 @@ __device__ __forceinline__ void unit_energy(const Lds& L, const HamDev& H, doubl
   static_assert(SEG >= 2 && SEG <= 5, "unit records hold five deposit masks");
   constexpr int U = kUnitTrip;
   static_assert(kUnitUnroll == 3 * kUnitTrip, "three trips per turn of the loop (ring of three table buffers)");
-  constexpr uint32_t TSTRIDE = (uint32_t)8 << LT;   // table bytes of one unit (units are stored in order)
+  constexpr uint32_t TSTRIDE = (uint32_t)8 << LT;   // table bytes of one unit
+  static_assert(U == 4, "the tables of a trip are interleaved [thread][unit of the trip]: two 16-byte loads per thread and trip");
+  constexpr uint32_t TRIP_BYTES = U * TSTRIDE;
   const int nu = __builtin_amdgcn_readfirstlane(H.n_units);
   if (nu <= 0) return;
   uint32_t tid = threadIdx.x;
@@ -1156,7 +1161,6 @@ __device__ __forceinline__ void unit_energy(const Lds& L, const HamDev& H, doubl
   uint32_t tsh[SEG];
 #pragma unroll
   for (int i = 0; i < SEG; ++i) tsh[i] = tid << (4 + i);
-  const uint32_t tid8 = tid << 3;
   // A trip = U units.  Table values come from L2 two trips ahead (ring of three register buffers, the loop body is
   // three trips so that the buffer indices are static).  The records of the next trip are requested into the SAME
   // scalar registers once the addresses of this trip are formed, and land while its LDS reads are in flight
@@ -1165,10 +1169,16 @@ __device__ __forceinline__ void unit_energy(const Lds& L, const HamDev& H, doubl
   u32x8_t R[U];
 #pragma unroll
   for (int j = 0; j < U; ++j) {
-    d[0][j] = buf_load_d(ru, tid8, (uint32_t)j * TSTRIDE);
-    d[1][j] = buf_load_d(ru, tid8, (uint32_t)(U + j) * TSTRIDE);
     R[j] = rec[j];
   }
+  const uint32_t tid32 = tid << 5;      // the thread's U table values of a trip are 32 contiguous bytes
+  auto load_trip = [&](double (&dst)[U], uint32_t first_unit) {
+    const uint32_t soff = (first_unit / U) * TRIP_BYTES;
+    const double2 lo = buf_load_d2(ru, tid32, soff), hi = buf_load_d2(ru, tid32 + 16u, soff);
+    dst[0] = lo.x; dst[1] = lo.y; dst[2] = hi.x; dst[3] = hi.y;
+  };
+  load_trip(d[0], 0u);
+  load_trip(d[1], (uint32_t)(U < nu ? U : 0));
   const int last = nu - U;       // first unit of the last trip
   for (int u = 0; u < nu; u += 3 * U) {
 #pragma unroll
@@ -1201,8 +1211,7 @@ __device__ __forceinline__ void unit_energy(const Lds& L, const HamDev& H, doubl
         pb[j] = lds_load_abs(a[j]);
         pa[j] = lds_load_abs(ax[j]);
       }
-#pragma unroll
-      for (int j = 0; j < U; ++j) d[(k + 2) % 3][j] = buf_load_d(ru, tid8, (uint32_t)(u2 + j) * TSTRIDE);
+      load_trip(d[(k + 2) % 3], (uint32_t)u2);
       __builtin_amdgcn_sched_barrier(0);
       const const_u32x8* rn = rec + u1;
 #pragma unroll
