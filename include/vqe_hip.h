@@ -130,6 +130,11 @@ int vqe_set_noise(vqe_t* h, double p1, double p2, uint64_t seed);
  * vqe_batch_run_minimize / _env_step (COBYLA then driven by the host on the exact energies).  The seed of
  * vqe_set_noise and vqe_set_shot_noise play no part in mode 1. */
 int vqe_set_noise_mode(vqe_t* h, int mode);
+/* host only (needs no device): the superoperator blocks the exact channel mode would sweep for this circuit - windows[2k],
+ * windows[2k+1] = the two qubits (a, b) of block k, S[k][2][16][16] = real and imaginary part of its 16 x 16 matrix, entry
+ * index = ket_a + 2 ket_b + 4 bra_a + 8 bra_b.  windows == NULL or S == NULL: only the count.  For tests of the fusion. */
+int vqe_dm_plan(int n_qubits, int n_gates, const int32_t* kind, const int32_t* q0, const int32_t* q1, const int32_t* param_idx,
+                const double* theta, double p1, double p2, int cap_blocks, int32_t* n_blocks, int32_t* windows, double* S);
 /* out[0] = the mode, out[1] = superoperator blocks (sweeps over rho) of the last exact-mode evaluation; for the
  * caller's roofline arithmetic (a sweep reads and writes 4^n complex128) */
 int vqe_noise_mode_info(vqe_t* h, int32_t out[2]);

@@ -44,6 +44,8 @@ SIGNATURES = {
     "vqe_comm_destroy": (C.c_int, [vp]),
     "vqe_set_noise_mode": (C.c_int, [vp, C.c_int]),
     "vqe_noise_mode_info": (C.c_int, [vp, c_i32p]),
+    "vqe_dm_plan": (C.c_int, [C.c_int, C.c_int, c_i32p, c_i32p, c_i32p, c_i32p, c_f64p, C.c_double, C.c_double, C.c_int, c_i32p,
+                              c_i32p, c_f64p]),
     "vqe_set_init_state_dev": (C.c_int, [vp, vp]),
     "vqe_get_state_dev": (C.c_int, [vp, c_f64p, vp]),
     "vqe_set_term_shard": (C.c_int, [vp, C.c_int, C.c_int]),

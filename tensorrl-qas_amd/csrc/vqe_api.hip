@@ -1629,6 +1629,33 @@ int vqe_set_noise_mode(vqe_t* h, int mode) {
   return VQE_OK;
 }
 
+int vqe_dm_plan(int n_qubits, int n_gates, const int32_t* kind, const int32_t* q0, const int32_t* q1, const int32_t* pidx,
+                const double* theta, double p1, double p2, int cap_blocks, int32_t* n_blocks, int32_t* windows, double* S) {
+  if (n_qubits < 2 || n_gates < 0 || !n_blocks || (n_gates > 0 && (!kind || !q0 || !q1 || !pidx))) return VQE_EINVAL;
+  std::vector<GateRec> g((size_t)n_gates);
+  for (int i = 0; i < n_gates; ++i) {
+    if (kind[i] < 0 || kind[i] > VQE_GATE_DEPOL2 || q0[i] < 0 || q0[i] >= n_qubits) return VQE_EINVAL;
+    const bool two = kind[i] == VQE_GATE_CNOT || kind[i] == VQE_GATE_DEPOL2;
+    if (two && (q1[i] < 0 || q1[i] >= n_qubits || q1[i] == q0[i])) return VQE_EINVAL;
+    if (kind[i] >= VQE_GATE_RX && kind[i] <= VQE_GATE_RZ && (pidx[i] < 0 || !theta)) return VQE_EINVAL;
+    g[i] = GateRec{kind[i], q0[i], q1[i], pidx[i]};
+  }
+  std::vector<DmBlockHost> blocks;
+  dm_make_blocks(n_qubits, g.data(), n_gates, theta, p1, p2, blocks);
+  *n_blocks = (int32_t)blocks.size();
+  if (!windows || !S) return VQE_OK;
+  if ((int)blocks.size() > cap_blocks) return VQE_EINVAL;
+  for (size_t k = 0; k < blocks.size(); ++k) {
+    windows[2 * k] = blocks[k].a;
+    windows[2 * k + 1] = blocks[k].b;
+    for (int r = 0; r < 16; ++r) for (int c = 0; c < 16; ++c) {
+      S[k * 512 + r * 16 + c] = blocks[k].S.m[r][c].real();
+      S[k * 512 + 256 + r * 16 + c] = blocks[k].S.m[r][c].imag();
+    }
+  }
+  return VQE_OK;
+}
+
 int vqe_noise_mode_info(vqe_t* h, int32_t out[2]) {
   if (!h || !out) return VQE_EINVAL;
   out[0] = h->noise_mode;

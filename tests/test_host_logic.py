@@ -250,3 +250,46 @@ def test_chain_generators_npz_writer_and_lanczos(tmp_path):
     assert conf["problem"]["ham_type"] == "tfim_j1_h0.05" and conf["env"]["num_qubits"] == 6
     assert os.path.exists(os.path.join(conf["env"]["data_root"], "mol_data", "tfim_j1_h0.05_6q.npz"))
     assert os.path.exists(os.path.join(conf["env"]["data_root"], "init_state_circ", "init_tfim_j1_h0.05_6q_TNbond2.qasm"))
+
+
+def test_exact_channel_block_fusion_on_the_host():
+    """vqe_dm_plan (host only): the two-qubit-window superoperator blocks of the exact channel mode, applied with numpy to
+    rho as the device sweep does (entry index = ket_a + 2 ket_b + 4 bra_a + 8 bra_b), reproduce the oracle's channel
+    evolution; blocks on disjoint windows stay open side by side, so there are fewer blocks than window changes."""
+    import ctypes as C
+    import vqe_oracle as vo
+    from helpers import random_gates, random_state
+    from tensorrl_qas_amd import _lib
+    lib = _lib.load()
+    for n, G, seed in ((3, 12, 0), (5, 30, 1), (6, 40, 2)):
+        rng = np.random.default_rng(seed)
+        psi0 = random_state(n, rng)
+        base = random_gates(n, G, rng)
+        kind, q0, q1, pidx = [], [], [], []
+        for k, a, b, p in zip(*base[:4]):
+            kind += [k, 5 if k == 0 else 4]; q0 += [a, a]; q1 += [b, b if k == 0 else -1]; pidx += [p, -1]
+        kind, q0, q1, pidx = (np.array(v, np.int32) for v in (kind, q0, q1, pidx))
+        th = base[4]
+        p1, p2 = 0.07, 0.11
+        nb = C.c_int32()
+        i32 = lambda a: a.ctypes.data_as(_lib.c_i32p)
+        thp = th.ctypes.data_as(_lib.c_f64p)
+        assert lib.vqe_dm_plan(n, kind.size, i32(kind), i32(q0), i32(q1), i32(pidx), thp, p1, p2, 0, C.byref(nb), None, None) == 0
+        win = np.zeros(2 * nb.value, np.int32)
+        S = np.zeros((nb.value, 2, 16, 16))
+        assert lib.vqe_dm_plan(n, kind.size, i32(kind), i32(q0), i32(q1), i32(pidx), thp, p1, p2, nb.value, C.byref(nb), i32(win),
+                               S.ctypes.data_as(_lib.c_f64p)) == 0
+        rho = np.outer(psi0, psi0.conj())                         # [ket, bra]
+        t = rho.T.reshape([2] * (2 * n))                          # flat = ket | bra << n: axes (bra_{n-1}..bra_0, ket_{n-1}..ket_0)
+        ax = lambda bit: 2 * n - 1 - bit                          # axis of index bit `bit`
+        for k in range(nb.value):
+            a, b = int(win[2 * k]), int(win[2 * k + 1])
+            M = (S[k, 0] + 1j * S[k, 1]).reshape([2] * 8)         # out (e3, e2, e1, e0), in (e3, e2, e1, e0); e0 = ket_a, e1 = ket_b, e2 = bra_a, e3 = bra_b
+            axes = [ax(b + n), ax(a + n), ax(b), ax(a)]
+            t = np.tensordot(M, t, axes=([4, 5, 6, 7], axes))
+            t = np.moveaxis(t, [0, 1, 2, 3], axes)
+        got = t.reshape(1 << n, 1 << n).T
+        ref = vo.run_circuit_dm(psi0, kind, q0, q1, pidx, th, p1, p2)
+        assert np.abs(got - ref).max() < 1e-12, (n, np.abs(got - ref).max())
+        changes = 1 + sum(1 for i in range(1, kind.size) if {q0[i], max(q1[i], q0[i])} - {q0[i - 1], max(q1[i - 1], q0[i - 1])})
+        assert 1 <= nb.value <= changes
