@@ -28,8 +28,10 @@
 
 #if defined(__HIPCC__)
 #define CBY_HD __host__ __device__ __forceinline__
+#define CBY_L __attribute__((always_inline))     // lambdas handed to walk_tiled: their operands are register arrays
 #else
 #define CBY_HD
+#define CBY_L
 #endif
 
 // The optimiser's arithmetic is kept un-contracted (no FMA fusion): that is what makes the
@@ -65,6 +67,7 @@ struct HostCtx {
   static constexpr int kPad = 1;   // inner loops run to exactly n
   static constexpr bool kSplit = false;   // no second lane to share a row with
   static constexpr bool kColumns = false; // (workgroup contexts: element-wise matrix passes run with the lanes along a row)
+  static constexpr bool kTile = false;    // (one-wave context on global arrays: row walks through an LDS transposition tile, walk_tiled)
   CBY_HD double pair_sum(double v) const { return v; }
   CBY_HD void lockstep() const {}   // see the one call site
 
@@ -104,7 +107,7 @@ CBY_HD int lead_dim(int nv) { return nv | 1; }
 // ... and for device arrays in GLOBAL memory a multiple of 8 doubles: every row then starts on a 64-byte boundary and
 // a batch of 8 consecutive elements of a row is ONE 64-byte sector (with the odd stride of the LDS layout every batch
 // straddled two: twice the L2 / HBM traffic of the row loops, which is what bounds the trainable regime).
-CBY_HD int lead_dim_global(int nv) { return (nv + 7) & ~7; }
+CBY_HD int lead_dim_global(int nv) { return (nv + 7) & ~7; }      // (nv is a multiple of the context's kPad: 16 -> rows are whole 128-byte lines)
 
 // Parallel contexts run the inner (serial) loops of a row to nv = n rounded up to kPad, in
 // batches of kPad with every load of a batch in flight together; the padding entries are
@@ -124,6 +127,7 @@ CBY_HD size_t scratch_doubles(int n, int pad = 8) {      // (odd leading dimensi
 // arrays are reached with ds_ instructions instead of flat ones.
 template <class Ctx, bool CHECK_INVERSE = false, class Real = double>
 struct CobylaM0 {
+  typedef Ctx Context;
   Ctx ctx;
   static constexpr int P = Ctx::kPad;   // batch of the inner loops (all loads of a batch, then the arithmetic)
   int n, nv, ld, maxfun;   // nv: inner-loop bound (n padded to Ctx::kPad) and index of the pole
@@ -178,6 +182,192 @@ struct CobylaM0 {
     }
   }
   CBY_HD size_t words() const { return (size_t)(st - x) + kStateDoubles; }
+
+  // ---- row walks through an LDS tile (contexts with kTile: ONE wavefront, arrays in global memory) -------------------
+  // The O(n^2) passes below whose lane owns a ROW j and walks its entries i (row norms, simi_j . dx, edge lengths, the
+  // rank-one update) read m[j * ld + i] with a stride of a whole row between neighbouring lanes: every load
+  // instruction touches 64 cache lines, and the CU's vector L1 looks lines up one per cycle - measured on the
+  // trainable H2O-8q workload (129 variables): 22 L1 accesses per load instruction, L1 busy 97 % of the kernel, 55 % of
+  // it waiting on misses, the wavefronts idle 70 % of theirs.  walk_tiled() moves a block of 64 rows x 16
+  // entries per step with the lanes ALONG the rows (16 loads of four 128-byte lines each, the next block already
+  // in flight), turns it round in LDS (row stride 17 doubles: conflict-free both ways) and hands lane l the 16 entries
+  // of row jb + l in index order - the arithmetic of a row, its order and therefore its bits are those of the plain
+  // loop; tests/cpp/cobyla_wave_emulation.cpp (plain loops) reproduces the device's trial points bit for bit.
+  //   m      : row-major array with leading dimension ld (simi, or sim whose "rows" are the vertices)
+  //   shared : vector every row meets (dx, or the rescaled row jdrop), staged in LDS behind the tile; or nullptr
+  //   init(j, acc) -> bool : per-row set-up (accumulators start at 0); false = the row is not walked
+  //   fn(j, i, v, u, acc)  : entry i of row j, v = m[j * ld + i], u = shared[i] (WRITE: may change v, the block is stored back)
+  //   post(j, walked, acc) : finish row j
+  // Needs nv % 16 == 0 (Ctx::kPad == 16) and rows 0..nv-1 present in m.
+  static constexpr int kAcc = 3;
+  static constexpr int kTileStride = 17;
+  static constexpr int kTileDoubles = 64 * kTileStride;      // followed by the shared vector (nv doubles)
+#ifndef CBY_TILE_FEW
+#define CBY_TILE_FEW 6
+#endif
+  static constexpr int kTileFewRows = CBY_TILE_FEW;
+  // ... and the passes whose lane owns a COLUMN i and walks down the rows (the linear model, the pole move) are
+  // coalesced as they stand but latency bound: a batch of loads, a round trip, its arithmetic, the next batch - and a
+  // lane on 129 variables owns columns l, l + 64, l + 128, three walks in a row, the last one for lane 0 alone.
+  // walk_cols() takes a lane's (up to kColsSide) columns side by side: a third of the round trips, three times the
+  // loads in flight in each.  Per column nothing changes.
+  //   load(k, i, v, u)    : the two operands of row k, column i
+  //   fn(k, i, v, u, acc) : arithmetic (and stores) of row k
+  //   post(i, acc)        : finish column i
+  static constexpr int kColsSide = 3;
+  template <int PB, class Init, class Load, class Fn, class Post>      // PB: rows per batch (divides nv)
+  CBY_HD void walk_cols(Init init, Load load, Fn fn, Post post) {
+    for (int ib = ctx.tid; ib < n; ib += 64 * kColsSide) {
+      int ic[kColsSide];
+      bool on[kColsSide];
+      double acc[kColsSide][kAcc];
+      CBY_FULL_UNROLL
+      for (int c = 0; c < kColsSide; ++c) {
+        ic[c] = ib + 64 * c;
+        on[c] = ic[c] < n;
+        acc[c][0] = 0.0; acc[c][1] = 0.0; acc[c][2] = 0.0;
+        if (on[c]) init(ic[c], acc[c]);
+      }
+      for (int k0 = 0; k0 < nv; k0 += PB) {
+        double v[kColsSide][PB], u[kColsSide][PB];
+        CBY_FULL_UNROLL
+        for (int c = 0; c < kColsSide; ++c)
+          if (on[c]) {
+            CBY_FULL_UNROLL
+            for (int q = 0; q < PB; ++q) load(k0 + q, ic[c], v[c][q], u[c][q]);
+          }
+        CBY_FULL_UNROLL
+        for (int c = 0; c < kColsSide; ++c)
+          if (on[c]) {
+            CBY_FULL_UNROLL
+            for (int q = 0; q < PB; ++q) fn(k0 + q, ic[c], v[c][q], u[c][q], acc[c]);
+          }
+      }
+      CBY_FULL_UNROLL
+      for (int c = 0; c < kColsSide; ++c)
+        if (on[c]) post(ic[c], acc[c]);
+    }
+  }
+
+  template <bool WRITE, bool SHARED, class Init, class Fn, class Post>
+  CBY_HD void walk_tiled(Real* m, int m_rows, const Real* shared, Init init, Fn fn, Post post) {
+    const int lane = ctx.tid;
+    auto* Tw = ctx.tile + (lane >> 4) * kTileStride + (lane & 15);     // lanes along the rows: row (lane >> 4) + 4 k, entry lane & 15
+    auto* Tr = ctx.tile + lane * kTileStride;                          // a lane per row
+    auto* S = ctx.tile + kTileDoubles;
+    ctx.tile_bind(m, m_rows, ld);
+    if (SHARED) {
+      for (int i = lane; i < nv; i += 64) S[i] = shared[i];
+      ctx.tile_sync();
+    }
+    for (int jb = 0; jb < n; jb += 64) {
+      const int j = jb + lane;
+      double acc[kAcc] = {0.0, 0.0, 0.0};
+      const bool on = j < n && init(j, acc);
+      // one block: g (fetched a block ago) -> LDS -> the lane's row, entries in index order -> (WRITE) back
+      auto block = [&](int i0, double (&g)[16]) CBY_L {
+        CBY_FULL_UNROLL
+        for (int k = 0; k < 16; ++k) Tw[4 * k * kTileStride] = g[k];
+        ctx.tile_sync();
+        if (on) {
+          CBY_FULL_UNROLL
+          for (int h = 0; h < 16; h += 8) {
+            double v[8], u[8];
+            CBY_FULL_UNROLL
+            for (int q = 0; q < 8; ++q) { v[q] = Tr[h + q]; u[q] = SHARED ? (double)S[i0 + h + q] : 0.0; }
+            CBY_FULL_UNROLL
+            for (int q = 0; q < 8; ++q) fn(j, i0 + h + q, v[q], u[q], acc);
+            if (WRITE) {
+              CBY_FULL_UNROLL
+              for (int q = 0; q < 8; ++q) Tr[h + q] = v[q];
+            }
+          }
+        }
+        if (WRITE) {
+          ctx.tile_sync();
+          double o[16];
+          CBY_FULL_UNROLL
+          for (int k = 0; k < 16; ++k) o[k] = Tw[4 * k * kTileStride];
+          ctx.tile_store(jb, i0, o);
+        }
+        ctx.tile_sync();
+      };
+      // few rows of the block want the walk (the 129th row of 129, one changed row in the acceptability test, the far
+      // vertices of the edge test): the wavefront fetches just those rows, lanes along each, into row buffers in the
+      // tile area - one round trip for all of them - and their owners walk them from LDS side by side
+      const unsigned long long mask = ctx.ballot(on);
+      const int cnt = ctx.popc(mask);
+      if (cnt == 0) {
+        if (j < n) post(j, on, acc);
+        continue;
+      }
+      if (cnt <= kTileFewRows && nv <= 192 && cnt * nv <= kTileDoubles) {
+        auto* R = ctx.tile;
+        int rowof[kTileFewRows];
+        {
+          unsigned long long mm = mask;
+          CBY_FULL_UNROLL
+          for (int t = 0; t < kTileFewRows; ++t) { rowof[t] = mm ? ctx.ctz(mm) : 0; mm &= mm - 1; }
+        }
+        double r[kTileFewRows][3];
+        CBY_FULL_UNROLL
+        for (int t = 0; t < kTileFewRows; ++t)
+          if (t < cnt) {
+            CBY_FULL_UNROLL
+            for (int c = 0; c < 3; ++c) r[t][c] = lane + 64 * c < nv ? (double)m[(size_t)(jb + rowof[t]) * ld + lane + 64 * c] : 0.0;
+          }
+        CBY_FULL_UNROLL
+        for (int t = 0; t < kTileFewRows; ++t)
+          if (t < cnt) {
+            CBY_FULL_UNROLL
+            for (int c = 0; c < 3; ++c)
+              if (lane + 64 * c < nv) R[t * nv + lane + 64 * c] = r[t][c];
+          }
+        ctx.tile_sync();
+        if (on) {
+          auto* row = R + ctx.popc(mask & ((1ull << lane) - 1ull)) * nv;
+          for (int i0 = 0; i0 < nv; i0 += 8) {
+            double v[8], u[8];
+            CBY_FULL_UNROLL
+            for (int q = 0; q < 8; ++q) { v[q] = row[i0 + q]; u[q] = SHARED ? (double)S[i0 + q] : 0.0; }
+            CBY_FULL_UNROLL
+            for (int q = 0; q < 8; ++q) fn(j, i0 + q, v[q], u[q], acc);
+            if (WRITE) {
+              CBY_FULL_UNROLL
+              for (int q = 0; q < 8; ++q) row[i0 + q] = v[q];
+            }
+          }
+        }
+        if (WRITE) {
+          ctx.tile_sync();
+          CBY_FULL_UNROLL
+          for (int t = 0; t < kTileFewRows; ++t)
+            if (t < cnt) {
+              CBY_FULL_UNROLL
+              for (int c = 0; c < 3; ++c)
+                if (lane + 64 * c < nv) m[(size_t)(jb + rowof[t]) * ld + lane + 64 * c] = R[t * nv + lane + 64 * c];
+            }
+        }
+        ctx.tile_sync();
+        if (j < n) post(j, on, acc);
+        continue;
+      }
+      // two register buffers in turn (no copies: a copy would wait for the block just requested)
+      double ga[16], gb[16];
+      // (no branch around a fetch: the wait-count pass would then assume the older buffer's loads are the newest
+      // and wait for everything; a fetch past the end of the rows brings values nobody uses)
+      ctx.tile_fetch(jb, 0, ga);
+      int i0 = 0;
+      for (; i0 + 32 <= nv; i0 += 32) {
+        ctx.tile_fetch(jb, i0 + 16, gb);
+        block(i0, ga);
+        ctx.tile_fetch(jb, i0 + 32, ga);
+        block(i0 + 16, gb);
+      }
+      if (i0 < nv) block(i0, ga);
+      if (j < n) post(j, on, acc);
+    }
+  }
 
   CBY_HD void save_state() {
     if (ctx.tid == 0) {
@@ -358,6 +548,25 @@ struct CobylaM0 {
           vcol = -2;   // every vertex moves relative to the new pole
           vrow = (vrow == -1 || vrow == nbest) ? nbest : -2;   // row nbest of simi is replaced below
           if (ctx.tid == 0) { const double t = datmat[nv]; datmat[nv] = datmat[nbest]; datmat[nbest] = t; }
+          bool walked_cols = false;
+          if constexpr (Ctx::kTile) {
+            if (!split) {
+              walk_cols<8>(
+                  [&](int i, double* acc) CBY_L {
+                    const double temp = SIM(i, nbest);
+                    SIM(i, nv) += temp;
+                    acc[1] = temp;
+                  },
+                  [&](int k, int i, double& v, double& u) CBY_L { v = SIM(i, k); u = SIMI(k, i); },
+                  [&](int k, int i, double v, double u, double* acc) CBY_L { SIM(i, k) = v - acc[1]; acc[0] -= u; },
+                  [&](int i, double* acc) CBY_L {
+                    SIM(i, nbest) = -acc[1];   // (old vertex nbest = new pole: 0 - temp)
+                    w[i] = acc[0];
+                  });
+              walked_cols = true;
+            }
+          }
+          if (!walked_cols)
           for (int i = rlane; i < n; i += rstep) {
             const double temp = SIM(i, nbest);
             // two lanes may share row i (kSplit): both must have read SIM(i, nbest) before its owner
@@ -394,6 +603,20 @@ struct CobylaM0 {
         CBY_STAMP(3);
         // ---- linear model: a = -grad
         const double fp = datmat[nv];
+        bool walked_cols = false;
+        if constexpr (Ctx::kTile) {
+          if (!split) {
+            auto* S = ctx.tile + kTileDoubles;      // the function values where every lane finds them
+            for (int j = ctx.tid; j < nv; j += 64) S[j] = datmat[j];
+            ctx.tile_sync();
+            walk_cols<8>([&](int, double*) CBY_L {},
+                      [&](int j, int i, double& v, double& u) CBY_L { v = S[j]; u = SIMI(j, i); },   // (rows n..nv-1 of simi are zero)
+                      [&](int, int, double v, double u, double* acc) CBY_L { acc[0] += (v - fp) * u; },
+                      [&](int i, double* acc) CBY_L { a[i] = -acc[0]; });
+            walked_cols = true;
+          }
+        }
+        if (!walked_cols)
         for (int i = rlane; i < n; i += rstep) {
           double temp = 0.0;
           for (int j0 = ilo; j0 < ihi; j0 += P) {   // (rows n..nv-1 of simi are zero)
@@ -411,6 +634,29 @@ struct CobylaM0 {
         parsig = 0.25 * rho;
         pareta = 2.1 * rho;
         int flag_bad = 0;
+        bool walked_tiles = false;
+        if constexpr (Ctx::kTile) {
+          if (!split) {
+            // (two walks: the row norms of simi, then the vertex norms of sim for the rows that want them)
+            walk_tiled<false, false>(
+                simi, nv, nullptr,
+                [&](int j, double*) CBY_L { return !kIncrementalEta || vrow == -2 || j == vrow || vcol == -2 || j == vcol; },
+                [&](int, int, double& v, double, double* acc) CBY_L { acc[0] += v * v; },
+                [&](int j, bool walked, double* acc) CBY_L {
+                  if (walked) vsig[j] = 1.0 / sqrt(acc[0]);
+                });
+            walk_tiled<false, false>(
+                sim, nv + 1, nullptr,
+                [&](int j, double*) CBY_L { return !kIncrementalEta || vcol == -2 || j == vcol; },
+                [&](int, int, double& v, double, double* acc) CBY_L { acc[0] += v * v; },
+                [&](int j, bool walked, double* acc) CBY_L {
+                  if (walked) veta[j] = sqrt(acc[0]);
+                  if (vsig[j] < parsig || veta[j] > pareta) flag_bad = 1;
+                });
+            walked_tiles = true;
+          }
+        }
+        if (!walked_tiles)
         for (int j = rlane; j < n; j += rstep) {
           double wsig = 0.0, weta = 0.0;
           const bool need_eta = !kIncrementalEta || vcol == -2 || j == vcol;
@@ -493,6 +739,23 @@ struct CobylaM0 {
         if (f == vmold) { prerem = 0.0; trured = 0.0; }
         // ---- which vertex (if any) does x(*) replace
         double ratio = (trured <= 0.0) ? 1.0 : 0.0;
+        bool walked_tiles = false;
+        if constexpr (Ctx::kTile) {
+          if (!split) {
+            walk_tiled<false, true>(
+                simi, nv, dx, [&](int, double*) CBY_L { return true; },
+                [&](int, int, double& v, double u, double* acc) CBY_L { acc[0] += v * u; },
+                [&](int j, bool, double* acc) CBY_L {
+                  double t = acc[0];
+                  tdot[j] = t;
+                  t = fabs(t);
+                  w[j] = t;
+                  sigbar[j] = t * vsig[j];
+                });
+            walked_tiles = true;
+          }
+        }
+        if (!walked_tiles)
         for (int j = rlane; j < n; j += rstep) {
           double t = 0.0;
           for (int i0 = ilo; i0 < ihi; i0 += P) {
@@ -512,6 +775,25 @@ struct CobylaM0 {
         int jd = ctx.arg_first(n, [&](int j) { return w[j]; }, ratio, true, &ratio);
         ctx.sync();
         CBY_STAMP(0);
+        walked_tiles = false;
+        if constexpr (Ctx::kTile) {
+          if (!split) {
+            walk_tiled<false, true>(
+                sim, nv + 1, dx,
+                [&](int j, double* acc) CBY_L {      // acc[1]: the value of a row that is not walked
+                  acc[1] = -1.0;
+                  if (sigbar[j] >= parsig || sigbar[j] >= vsig[j]) {
+                    acc[1] = veta[j];
+                    return trured > 0.0;
+                  }
+                  return false;
+                },
+                [&](int, int, double& v, double u, double* acc) CBY_L { const double d = u - v; acc[0] += d * d; },
+                [&](int j, bool walked, double* acc) CBY_L { w[j] = walked ? sqrt(acc[0]) : acc[1]; });
+            walked_tiles = true;
+          }
+        }
+        if (!walked_tiles)
         for (int j = rlane; j < n; j += rstep) {
           double t = -1.0;
           if (sigbar[j] >= parsig || sigbar[j] >= vsig[j]) {
@@ -602,6 +884,34 @@ struct CobylaM0 {
       vrow = -2;   // (the row norms are not formed on this path)
       ctx.sync();
       return;
+    }
+    if constexpr (Ctx::kTile) {
+      if (!split) {
+        if (!have_tdot)
+          walk_tiled<false, true>(
+              simi, nv, dx, [&](int j, double*) CBY_L { return j != jdrop; },
+              [&](int, int, double& v, double u, double* acc) CBY_L { acc[0] += v * u; },
+              [&](int j, bool walked, double* acc) CBY_L {
+                if (walked) tdot[j] = acc[0];      // (read back by the same lane below)
+              });
+        // row jdrop (rescaled above) rides along with a factor of zero: its entries stay as they are, its norm - the
+        // same sum in the same order as the owner's loop of the plain path - comes out of the same walk
+        walk_tiled<true, true>(
+            simi, nv, simi + (size_t)jdrop * ld,
+            [&](int j, double* acc) CBY_L {
+              acc[1] = j == jdrop ? 0.0 : (double)tdot[j];
+              return true;
+            },
+            [&](int j, int, double& v, double u, double* acc) CBY_L {
+              const double nw = v - acc[1] * u;
+              acc[0] += nw * nw;     // the row norm the next acceptability test wants: same order as there
+              v = j == jdrop ? v : nw;
+            },
+            [&](int j, bool, double* acc) CBY_L { vsig[j] = 1.0 / sqrt(acc[0]); });
+        vrow = -1;
+        ctx.sync();
+        return;
+      }
     }
     for (int j = rlane; j < n; j += rstep) {
       if (j == jdrop) continue;

@@ -647,15 +647,12 @@ int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
   // register path: the raw ops are staged in the (idle) state region, 2^n records at most
   if (N >= kRegMinQubits && (size_t)A.max_ops > ((size_t)1 << N))
     return fail(h, VQE_EINVAL, "circuit too large for the LDS-resident path (more than 2^n rotations)");
-  // 256-thread workgroups below the register path (n = 9 by default) with more than 64 parameters in a circuit (the
-  // trainable regime): the variant whose optimiser update runs on the whole workgroup (StagedCobyla<N, WIDE>).
-  // One-wave workgroups (n <= kOneWaveMaxQubits) have no second wave to spread it over.
-  // One-wave workgroups (n <= kOneWaveMaxQubits) can run that variant too (VQE_WIDE64=1; round 2's attempt hung on an
-  // uninitialised pointer, see StagedCobyla::call): off by default until it measures faster than the one-wave context.
+  // More than 64 parameters in a circuit (the trainable regime): the WIDE variant of the kernel - on 256-thread
+  // workgroups the optimiser update runs on the whole workgroup (BlockCtx), on one-wave workgroups (n <= 9) the lanes
+  // walk their rows of the matrices side by side (WaveRowsCtx).  The plain variant keeps neither (registers).
   constexpr bool kHasWide = N >= 6;
   static const bool wide_on = [] { const char* e = std::getenv("VQE_WIDE_UPDATE"); return !(e && e[0] == '0'); }();   // A/B knob
-  static const bool wide64_on = [] { const char* e = std::getenv("VQE_WIDE64"); return e && e[0] == '1'; }();
-  const bool wide = kHasWide && wide_on && which == 1 && A.max_params > 64 && (Geo<N>::NT >= 256 || wide64_on);
+  const bool wide = kHasWide && wide_on && which == 1 && A.max_params > 64;
   const bool noisy = A.noise.p1 > 0.0 || A.noise.p2 > 0.0;
   constexpr bool kW = false;     // up to 64 parameters per circuit: the instantiation without the workgroup-wide update
   const void* fn = which == 0 ? (const void*)k_lds_energy<N>
@@ -740,7 +737,7 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   for (int b = 0; b < batch; ++b) {
     sbeg[b] = stot;
     stot += (int64_t)cby::scratch_doubles(pcnt[b], 16);   // the larger of the device contexts' paddings
-    stot = (stot + 7) & ~(int64_t)7;  // 64-byte alignment: rows of the optimiser's global arrays are whole sectors
+    stot = (stot + 15) & ~(int64_t)15;  // 128-byte alignment: rows of the optimiser's global arrays are whole sectors / lines
     max_par = std::max(max_par, (int)pcnt[b]);
     int ops = 0;
     for (int64_t i = gbeg[b]; i < gbeg[b] + gcnt[b]; ++i) {

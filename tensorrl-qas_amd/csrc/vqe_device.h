@@ -93,6 +93,7 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 typedef double d2v_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const unsigned char lds_cbyte;
+typedef __attribute__((address_space(3))) double lds_double;
 
 enum : int { G_CNOT = 0, G_RX = 1, G_RY = 2, G_RZ = 3, G_DEPOL1 = 4, G_DEPOL2 = 5 };
 enum : int { OP_RX = 1, OP_RY = 2, OP_RZ = 3, OP_PZ = 4, OP_NOP = 6 };   // (5 = OP_RELAYOUT, vqe_reg.h)
@@ -268,6 +269,7 @@ struct WaveCtx {
   static constexpr int kPad = 8;   // inner loops in batches of 8, matrices zero-padded (cobyla_m0.h)
   static constexpr bool kSplit = true;   // <= 32 rows: lanes l and l + 32 share a row
   static constexpr bool kColumns = false;
+  static constexpr bool kTile = false;
   // v + (the value of v in lane ^ 32)
   __device__ __forceinline__ double pair_sum(double v) const {
     const int lo = __double2loint(v), hi = __double2hiint(v);
@@ -320,6 +322,62 @@ struct WaveCtx {
   }
 };
 
+// The one-wave context of the TRAINABLE regime on the one-wave kernels (n <= 9; 129 parameters for H2O-8q): arrays in
+// global memory, row walks through an LDS transposition tile (cobyla_m0.h: walk_tiled) instead of one lane per row -
+// a lane per row touches 64 cache lines per load instruction and the CU's vector L1 looks them up one per cycle, which
+// is what bounded this regime.  Same arithmetic in the same order as WaveCtx (bit-identical trial points); padding to
+// 16 so that rows are whole 128-byte lines.  Only the kernel variant launched for such batches carries it (registers,
+// LDS for the tile).
+struct WaveRowsCtx : WaveCtx {
+  static constexpr int kPad = 16;
+  static constexpr bool kSplit = false;      // (only problems with more than 32 variables come here)
+#ifndef VQE_ROWS_TILE
+#define VQE_ROWS_TILE 1
+#endif
+  static constexpr bool kTile = VQE_ROWS_TILE != 0;
+  lds_double* tile;      // kTileDoubles + nv doubles
+  // block transfers of walk_tiled: buffer loads / stores through a descriptor of the whole array - rows beyond it read
+  // as zero and are not written (no predicates), the part of the address that is the same for all lanes sits in a
+  // scalar register (no 64-bit vector address arithmetic: the plain-C version of this walk spent 130 vector
+  // instructions per block on addresses)
+  __amdgpu_buffer_rsrc_t t_rs;
+  uint32_t t_voff, t_row4;      // byte offset of this lane's (row lane >> 4, entry lane & 15); bytes of four rows
+  uint32_t t_ld8;
+  __device__ __forceinline__ void tile_bind(const double* m, int m_rows, int ld) {
+    t_rs = __builtin_amdgcn_make_buffer_rsrc((void*)m, 0, m_rows * ld * 8, 0x00020000);
+    t_ld8 = (uint32_t)ld * 8u;
+    t_voff = (uint32_t)(tid >> 4) * t_ld8 + (uint32_t)(tid & 15) * 8u;
+    t_row4 = 4u * t_ld8;
+  }
+  __device__ __forceinline__ void tile_fetch(int jb, int i0, double (&g)[16]) const {
+    const uint32_t base = (uint32_t)jb * t_ld8 + (uint32_t)i0 * 8u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(t_rs, (int)t_voff, (int)(base + (uint32_t)k * t_row4), 0);
+      g[k] = __hiloint2double(v[1], v[0]);
+    }
+  }
+  __device__ __forceinline__ void tile_store(int jb, int i0, const double (&o)[16]) const {
+    const uint32_t base = (uint32_t)jb * t_ld8 + (uint32_t)i0 * 8u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      v2i_t v;
+      v[0] = __double2loint(o[k]); v[1] = __double2hiint(o[k]);
+      __builtin_amdgcn_raw_buffer_store_b64(v, t_rs, (int)t_voff, (int)(base + (uint32_t)k * t_row4), 0);
+    }
+  }
+  // LDS instructions of one wavefront execute in order: only the compiler has to be kept from moving them (and
+  // nothing waits for the global loads of the next block, which a fence would)
+  __device__ __forceinline__ void tile_sync() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+  __device__ __forceinline__ unsigned long long ballot(bool v) const { return __ballot(v); }
+  __device__ __forceinline__ int popc(unsigned long long m) const { return __popcll(m); }
+  __device__ __forceinline__ int ctz(unsigned long long m) const { return __builtin_ctzll(m); }
+};
+constexpr size_t kCobTileBytes = (size_t)(64 * 17) * 8;     // cby::CobylaM0::kTileDoubles doubles, + the shared vector
+__host__ __device__ inline size_t cobyla_tile_bytes(int n, int max_params) {
+  return geo_one_wave(n) && max_params > 64 ? kCobTileBytes + (size_t)cby::padded(max_params, 16) * 8 : 0;
+}
+
 // Workgroup-wide context of cobyla_m0.h for LARGE problems (more rows than a wave has lanes,
 // matrices in the global scratch - the trainable-path regime, ~129 parameters): every thread
 // takes a row, reductions go through LDS and s_barrier.  With one wave the row loops would run
@@ -333,6 +391,7 @@ struct BlockCtx {
   static constexpr int kPad = 8;    // (16 - twice the loads in flight per batch - measured +5 % at 12 qubits / 202 variables)
   static constexpr bool kSplit = false;
   static constexpr bool kColumns = true;   // element-wise matrix passes with the lanes along a row (cobyla_m0.h: update_simi)
+  static constexpr bool kTile = false;
   __device__ __forceinline__ double pair_sum(double v) const { return v; }
   __device__ __forceinline__ void lockstep() const {}   // kSplit = false: a row has one owner
   __device__ __forceinline__ void sync() const { __syncthreads(); }
@@ -417,6 +476,7 @@ struct Lds {
   uint32_t* sb;     // [16] scheduler scratch
   uint16_t* sidx;   // [max_ops] position of raw op k in the executed list (sched for n >= 10, ops below)
   double* cob;      // the optimiser's arrays (cobyla_resident_bytes), or nullptr
+  double* tile;     // transposition tile of the one-wave optimiser on more than 64 variables (cobyla_tile_bytes), or nullptr
 };
 
 // n >= 10: the raw ops only live while the schedule is built, in the (idle) state region: in its
@@ -445,7 +505,7 @@ __host__ __device__ inline size_t cobyla_resident_bytes(int n, int max_ops, int 
 }
 __host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params, int n_groups) {
   const size_t r = cobyla_resident_bytes(n, max_ops, max_params, n_groups);
-  return ((lds_bytes_base(n, max_ops, max_params, n_groups) + 15) & ~(size_t)15) + r;
+  return ((lds_bytes_base(n, max_ops, max_params, n_groups) + 15) & ~(size_t)15) + r + cobyla_tile_bytes(n, max_params);
 }
 
 __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, int max_params, int n_groups) {
@@ -474,6 +534,10 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, in
   l.cob = cobyla_resident_bytes(n, max_ops, max_params, n_groups)
               ? (double*)((unsigned char*)l.psi + ((lds_bytes_base(n, max_ops, max_params, n_groups) + 15) & ~(size_t)15))
               : nullptr;
+  l.tile = cobyla_tile_bytes(n, max_params)
+               ? (double*)((unsigned char*)l.psi + ((lds_bytes_base(n, max_ops, max_params, n_groups) + 15) & ~(size_t)15) +
+                           cobyla_resident_bytes(n, max_ops, max_params, n_groups))
+               : nullptr;
   return l;
 }
 
@@ -1057,7 +1121,7 @@ __device__ __forceinline__ double lds_energy(const Lds& L, const HamDev& H) {
   const int g1 = g0 + H.n_real;        // multiple of PD groups with real tables
   energy_real_lds<N>(L, tables, g0, g1, acc0, acc1);
   energy_imag_lds<N>(L, tables, g1, H.n_groups, acc0);
-  if constexpr (N >= kUnitMinQubits) unit_energy<N>(L, H, acc0, acc1);      // the mostly-zero groups (state in logical order here)
+  if constexpr (N >= kUnitMinQubits && N - 1 - Geo<N>::LT >= 1) unit_energy<N>(L, H, acc0, acc1);      // the mostly-zero groups (state in logical order here)
   return block_sum<Geo<N>::NW>(acc0 + acc1, L.red);
 }
 
@@ -1406,7 +1470,6 @@ __device__ __forceinline__ double lds_evaluate(const BatchArgs& A, const Lds& L,
 
 // COBYLA with its matrices staged into the state region of LDS while the state is dead
 // (between two evaluations); falls back to the global scratch when they do not fit.
-typedef __attribute__((address_space(3))) double lds_double;
 struct NoSide { __device__ __forceinline__ void operator()() const {} };
 
 // K double2 values that stay in registers: members of a recursive struct are scalars from the start (a plain member
@@ -1431,12 +1494,22 @@ template <int N, bool WIDE = (N >= 10 && Geo<N>::NT >= 256)>
 struct StagedCobyla {
   static constexpr int kThreads = Geo<N>::NT;
   typedef cby::CobylaM0<WaveCtx, false, lds_double> CobL;   // arrays in LDS (ds_ instructions)
+  // WIDE on a one-wave workgroup: no second wave to spread the update over - the lanes walk their rows side by side
+  static constexpr bool kBlock = WIDE && Geo<N>::NT >= 256;
+  static constexpr bool kRowsG = WIDE && Geo<N>::NT == 64;
   typedef cby::CobylaM0<WaveCtx, false, double> CobG;       // arrays in the global scratch, one wave
+  // ... and with the row / column walks of the trainable regime (WaveRowsCtx): problems with more than 32 variables,
+  // i.e. those whose rows are not split over lane pairs - the padding to 16 moves the split point of a pair, nothing
+  // else: for every other problem the two contexts produce the same bits, so a circuit's result does not depend on
+  // which kernel variant its batch selected
+  typedef cby::CobylaM0<WaveRowsCtx, false, double> CobR;
+  __device__ __forceinline__ bool rows_ctx() const { return kRowsG && n > 32; }
   typedef cby::CobylaM0<BlockCtx<Geo<N>::NT>, false, double> CobB;   // the same, whole workgroup (more rows than a wave has lanes)
   double* red;     // LDS words of the block reductions
   bool block;      // more rows than a wave has lanes: workgroup-wide context on the global scratch
   double* gmem;    // per-problem scratch; x[] is its first array
   double* lmem;    // the (dead) state region of LDS
+  double* tile;    // LDS transposition tile of the one-wave context on more than 64 variables (kRowsG)
   int* pub;        // LDS: what wave 0 publishes to the workgroup after a call
   int n, words;
   bool staged;
@@ -1459,18 +1532,21 @@ struct StagedCobyla {
     gmem = global_scratch;
     resident = L.cob != nullptr;
     lmem = resident ? L.cob : (double*)L.psi;
+    tile = L.tile;
     pub = (int*)(L.red + 8);
     n = n_;
     words = (int)cby::scratch_doubles(n, WaveCtx::kPad);
     red = L.red;
-    block = WIDE && n > 64;
+    block = kBlock && n > 64;
     staged = resident || (!block && (size_t)words * 8 <= ((size_t)16 << N));
     if (block) words = (int)cby::scratch_doubles(n, BlockCtx<Geo<N>::NT>::kPad);
     // arrays that stay in the global scratch use the 64-byte row layout (cobyla_m0.h: lead_dim_global)
     // (one-wave context only: with a thread per row - BlockCtx - the aligned stride measured 3.5 % slower at 12 qubits /
     // 202 variables, 4.6 % faster for the one-wave context at 8 qubits / 129 variables)
-    if (!staged && !block)
-      words = (int)cby::scratch_doubles_ld(n, WaveCtx::kPad, cby::lead_dim_global(cby::padded(n, WaveCtx::kPad)));
+    if (!staged && !block) {
+      const int pad = rows_ctx() ? CobR::P : CobG::P;      // (16 with the tile context: rows are whole 128-byte lines)
+      words = (int)cby::scratch_doubles_ld(n, pad, cby::lead_dim_global(cby::padded(n, pad)));
+    }
   }
   __device__ __forceinline__ double* x() const { return resident ? lmem : gmem; }
   // the optimiser's scalars as parked in the scratch (valid after start()/tell())
@@ -1583,7 +1659,8 @@ struct StagedCobyla {
     // the workgroup contexts reduce through LDS words.  (Round 2 tested `nth != 64` here to tell them from WaveCtx:
     // BlockCtx<64> has 64 threads too, so a one-wave instantiation of the workgroup-wide update ran arg_first / all_or
     // through an UNINITIALISED `red` pointer - the "hang" recorded in round 2)
-    if constexpr (!std::is_same<decltype(cob.ctx), WaveCtx>::value) cob.ctx.red = red;
+    if constexpr (!std::is_base_of<WaveCtx, decltype(cob.ctx)>::value) cob.ctx.red = red;
+    if constexpr (decltype(cob.ctx)::kTile) cob.ctx.tile = (lds_double*)tile;
     // opaque copies: otherwise the array addresses bind() derives are loop invariants of the
     // evaluation loop, get hoisted out of it, spilled across the energy step (where registers
     // are scarcest) and reloaded from scratch inside every tell()
@@ -1612,14 +1689,16 @@ struct StagedCobyla {
 #ifdef VQE_STAMPS
     const long long t1 = clock64();
 #endif
-    if (WIDE && block) {
-      if constexpr (WIDE) {
+    if (kBlock && block) {
+      if constexpr (kBlock) {
         if (kThreads == 64 || (threadIdx.x >= 64 && threadIdx.x < 128)) side();
         call<FIRST, CobB>(gmem, f, rhobeg, rhoend, maxfun);     // all threads: contains barriers
       }
     } else if (threadIdx.x < 64) {
       if (staged) call<FIRST, CobL>((lds_double*)lmem, f, rhobeg, rhoend, maxfun);
-      else call<FIRST, CobG>(gmem, f, rhobeg, rhoend, maxfun);
+      else if (rows_ctx()) {
+        if constexpr (kRowsG) call<FIRST, CobR>(gmem, f, rhobeg, rhoend, maxfun);
+      } else call<FIRST, CobG>(gmem, f, rhobeg, rhoend, maxfun);
       if constexpr (kThreads == 64) side();     // one-wave workgroups: no second wave to give the side job to
     } else if (threadIdx.x < 128) {
 #ifdef VQE_STAMPS

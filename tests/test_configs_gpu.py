@@ -342,6 +342,51 @@ def test_trainable_scale_12_qubits(tq):
 
 
 # ---- device COBYLA vs host COBYLA on the device's own energies ------------------------------------
+def _rotations(n, P, rng, p_cnot=0.15):
+    """A circuit with exactly P rotations (and CNOTs in between)."""
+    kind, q0, q1, pidx = [], [], [], []
+    for j in range(P):
+        kind.append(1 + int(rng.integers(3))), q0.append(int(rng.integers(n))), q1.append(-1), pidx.append(j)
+        if rng.random() < p_cnot:
+            c = int(rng.integers(n))
+            kind.append(0), q0.append(c), q1.append(int((c + 1 + rng.integers(n - 1)) % n)), pidx.append(-1)
+    return tuple(np.array(v, np.int32) for v in (kind, q0, q1, pidx)) + (rng.uniform(-np.pi, np.pi, P),)
+
+
+@pytest.mark.parametrize("n", [8, 9])
+def test_result_does_not_depend_on_the_batch_a_circuit_is_in(tq, n):
+    """One-wave kernels (n <= 9): a batch with a circuit of more than 64 parameters runs the kernel variant whose
+    optimiser walks the matrices through the LDS tile / column groups (WaveRowsCtx); the small circuits of
+    such a batch - LDS-staged arrays (P = 9), lane pairs per row (P = 20, 30), one lane per row in the global scratch
+    (P = 40, 60: rows context, padding 16 instead of 8) - must come out BIT for bit as they do in a batch of their own,
+    and the large ones as in any other batch composition."""
+    rng = np.random.default_rng(300 + n)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 25, rng)
+    small = [_rotations(n, P, rng) for P in (9, 20, 30, 40, 60)]
+    big = [_rotations(n, P, rng) for P in (70, 129)]
+    eng = _engine(tq, n, psi0, ham)
+
+    def run(cs, maxfun=90):
+        eng.batch_load([tq.Circuit(*c[:4], c[4].size) for c in cs], [c[4] for c in cs])
+        eng.batch_run_minimize(1.0, 1e-4, maxfun)
+        x, f, nfev = eng.batch_fetch()
+        off = np.concatenate([[0], np.cumsum([c[4].size for c in cs])])
+        return [(x[off[i]:off[i + 1]].copy(), float(f[i]), int(nfev[i])) for i in range(len(cs))]
+
+    alone = run(small)                       # plain variant (no circuit above 64 parameters)
+    mixed = run(small + big)                 # rows variant
+    for (xa, fa, na), (xm, fm, nm) in zip(alone, mixed[:len(small)]):
+        assert na == nm and fa == fm and np.array_equal(xa, xm)
+    again = run(big[::-1] + small[:1])       # another composition, another launch order
+    for (xa, fa, na), (xm, fm, nm) in zip(mixed[len(small):], again[:2][::-1]):
+        assert na == nm and fa == fm and np.array_equal(xa, xm)
+    for c, (x, f, nfev) in zip(big, mixed[len(small):]):          # ... and the values are energies of the returned points
+        e = vo.energy_pauli(vo.run_circuit(psi0, *c[:4], x), *ham)
+        assert abs(e - f) < 1e-10 and nfev == 90
+    eng.close()
+
+
 def _tie_free_gates(n, P, rng):
     """P rotations on DISTINCT (qubit, axis) pairs with CNOTs in between: no two parameters act
     alike, so COBYLA meets no exact ties (two equal simplex values / equally placed vertices are

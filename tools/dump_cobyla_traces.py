@@ -24,7 +24,11 @@ def write_trace(path, th, ft, xt, nf):
 # (n, P, seed, shot-noise sigma, maxfun): LDS-staged and global-scratch matrices, rows split over lane
 # pairs (2 P8 <= 64) and not, smooth and jumpy objective (the latter drives the geometry-step branches)
 CASES = ((12, 9, 3, 0.0, 200), (8, 10, 2, 0.5, 120), (5, 6, 1, 0.5, 80), (12, 9, 3, 0.5, 110), (10, 24, 6, 0.0, 110),
-         (8, 40, 8, 0.0, 90))
+         (8, 40, 8, 0.0, 90),
+         # one wave on MORE than 64 variables (the trainable regime of the one-wave kernels): the row walks go through
+         # the LDS transposition tile (cobyla_m0.h: walk_tiled) and must still be the plain loops bit for bit; the
+         # shot noise drives the geometry steps (update without a stored simi . dx)
+         (8, 129, 9, 0.0, 150), (8, 70, 4, 0.3, 150))
 
 
 def device_trace(n, P, seed, sigma, maxfun):
