@@ -68,6 +68,7 @@ struct HostCtx {
   static constexpr bool kSplit = false;   // no second lane to share a row with
   static constexpr bool kColumns = false; // (workgroup contexts: element-wise matrix passes run with the lanes along a row)
   static constexpr bool kTile = false;    // (one-wave context on global arrays: row walks through an LDS transposition tile, walk_tiled)
+  static constexpr bool kTileWalks = false;
   CBY_HD double pair_sum(double v) const { return v; }
   CBY_HD void lockstep() const {}   // see the one call site
 
@@ -214,16 +215,16 @@ struct CobylaM0 {
   //   load(k, i, v, u)    : the two operands of row k, column i
   //   fn(k, i, v, u, acc) : arithmetic (and stores) of row k
   //   post(i, acc)        : finish column i
-  static constexpr int kColsSide = 3;
+  static constexpr int kColsSide = Ctx::nth == 64 ? 3 : 1;      // (a workgroup context has a thread per column)
   template <int PB, class Init, class Load, class Fn, class Post>      // PB: rows per batch (divides nv)
   CBY_HD void walk_cols(Init init, Load load, Fn fn, Post post) {
-    for (int ib = ctx.tid; ib < n; ib += 64 * kColsSide) {
+    for (int ib = ctx.tid; ib < n; ib += Ctx::nth * kColsSide) {
       int ic[kColsSide];
       bool on[kColsSide];
       double acc[kColsSide][kAcc];
       CBY_FULL_UNROLL
       for (int c = 0; c < kColsSide; ++c) {
-        ic[c] = ib + 64 * c;
+        ic[c] = ib + Ctx::nth * c;
         on[c] = ic[c] < n;
         acc[c][0] = 0.0; acc[c][1] = 0.0; acc[c][2] = 0.0;
         if (on[c]) init(ic[c], acc[c]);
@@ -251,16 +252,17 @@ struct CobylaM0 {
 
   template <bool WRITE, bool SHARED, class Init, class Fn, class Post>
   CBY_HD void walk_tiled(Real* m, int m_rows, const Real* shared, Init init, Fn fn, Post post) {
-    const int lane = ctx.tid;
+    const int lane = ctx.tid & 63;      // (a workgroup context: every wavefront walks 64-row blocks of its own, through its own tile)
     auto* Tw = ctx.tile + (lane >> 4) * kTileStride + (lane & 15);     // lanes along the rows: row (lane >> 4) + 4 k, entry lane & 15
     auto* Tr = ctx.tile + lane * kTileStride;                          // a lane per row
-    auto* S = ctx.tile + kTileDoubles;
+    auto* S = ctx.shared;
     ctx.tile_bind(m, m_rows, ld);
     if (SHARED) {
-      for (int i = lane; i < nv; i += 64) S[i] = shared[i];
-      ctx.tile_sync();
+      ctx.tile_sync_all();      // (the previous walk's readers of S are done)
+      for (int i = ctx.tid; i < nv; i += Ctx::nth) S[i] = shared[i];
+      ctx.tile_sync_all();
     }
-    for (int jb = 0; jb < n; jb += 64) {
+    for (int jb = (ctx.tid >> 6) * 64; jb < n; jb += Ctx::nth) {
       const int j = jb + lane;
       double acc[kAcc] = {0.0, 0.0, 0.0};
       const bool on = j < n && init(j, acc);
@@ -604,11 +606,12 @@ struct CobylaM0 {
         // ---- linear model: a = -grad
         const double fp = datmat[nv];
         bool walked_cols = false;
-        if constexpr (Ctx::kTile) {
+        if constexpr (Ctx::kTile && Ctx::kTileWalks) {
           if (!split) {
-            auto* S = ctx.tile + kTileDoubles;      // the function values where every lane finds them
-            for (int j = ctx.tid; j < nv; j += 64) S[j] = datmat[j];
-            ctx.tile_sync();
+            auto* S = ctx.shared;      // the function values where every lane finds them
+            ctx.tile_sync_all();
+            for (int j = ctx.tid; j < nv; j += Ctx::nth) S[j] = datmat[j];
+            ctx.tile_sync_all();
             walk_cols<8>([&](int, double*) CBY_L {},
                       [&](int j, int i, double& v, double& u) CBY_L { v = S[j]; u = SIMI(j, i); },   // (rows n..nv-1 of simi are zero)
                       [&](int, int, double v, double u, double* acc) CBY_L { acc[0] += (v - fp) * u; },
@@ -635,7 +638,7 @@ struct CobylaM0 {
         pareta = 2.1 * rho;
         int flag_bad = 0;
         bool walked_tiles = false;
-        if constexpr (Ctx::kTile) {
+        if constexpr (Ctx::kTile && Ctx::kTileWalks) {
           if (!split) {
             // (two walks: the row norms of simi, then the vertex norms of sim for the rows that want them)
             walk_tiled<false, false>(
@@ -740,7 +743,7 @@ struct CobylaM0 {
         // ---- which vertex (if any) does x(*) replace
         double ratio = (trured <= 0.0) ? 1.0 : 0.0;
         bool walked_tiles = false;
-        if constexpr (Ctx::kTile) {
+        if constexpr (Ctx::kTile && Ctx::kTileWalks) {
           if (!split) {
             walk_tiled<false, true>(
                 simi, nv, dx, [&](int, double*) CBY_L { return true; },
@@ -776,7 +779,7 @@ struct CobylaM0 {
         ctx.sync();
         CBY_STAMP(0);
         walked_tiles = false;
-        if constexpr (Ctx::kTile) {
+        if constexpr (Ctx::kTile && Ctx::kTileWalks) {
           if (!split) {
             walk_tiled<false, true>(
                 sim, nv + 1, dx,
@@ -854,7 +857,7 @@ struct CobylaM0 {
     ctx.sync();
     for (int i = ctx.tid; i < n; i += ctx.nth) SIMI(jdrop, i) /= temp;
     ctx.sync();
-    if constexpr (Ctx::kColumns) {
+    if constexpr (Ctx::kColumns && !Ctx::kTile) {
       // Workgroup context: the update is element-wise, so it does not matter who does it - wave w takes rows
       // w, w + NW, ... with its lanes along the row (coalesced, every thread busy, nothing to reduce; a thread
       // per row walks 2 nv doubles through L2 with a stride of a whole row between neighbouring lanes).

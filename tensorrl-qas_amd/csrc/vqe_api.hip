@@ -75,7 +75,7 @@ struct vqe_handle {
   // resident batch
   int batch = 0;
   int64_t total_params = 0;
-  int max_ops = 0, max_params = 0;
+  int max_ops = 0, max_params = 0, max_pair = 0;
   std::vector<int64_t> h_par_begin;
   std::vector<int32_t> h_par_count;
   DevBuf<GateRec> d_gates;
@@ -638,7 +638,7 @@ int check_gates(vqe_t* h, int64_t n_gates, const int32_t* kind, const int32_t* q
 
 template <int N>
 int launch_lds(vqe_t* h, int which, const BatchArgs& A) {
-  size_t lds = lds_bytes(N, A.max_ops, A.max_params, A.ham.n_groups);
+  size_t lds = lds_bytes(N, A.max_ops, A.max_params, A.ham.n_groups, A.max_pair);
   // measurement knob: VQE_LDS_PAD=bytes of unused LDS per workgroup lowers the workgroups per CU
   static const long lds_pad = [] { const char* e = std::getenv("VQE_LDS_PAD"); return e ? std::atol(e) : 0L; }();
   if (lds_pad > 0) lds += (size_t)lds_pad;
@@ -715,6 +715,7 @@ BatchArgs make_args(vqe_t* h) {
   A.ham = h->ham;
   A.noise = h->noise;
   A.max_ops = h->max_ops;
+  A.max_pair = h->max_pair;
   A.max_params = h->max_params;
   A.state_out = h->d_state.p;
   A.dbg = h->d_dbg.p;
@@ -732,19 +733,21 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   int rc;
   std::vector<int64_t> sbeg(batch);
   int64_t stot = 0;
-  int max_ops = 1, max_par = 1;
+  int max_ops = 1, max_par = 1, max_pair = 0;
   std::vector<double> cost(batch);
   for (int b = 0; b < batch; ++b) {
     sbeg[b] = stot;
     stot += (int64_t)cby::scratch_doubles(pcnt[b], 16);   // the larger of the device contexts' paddings
     stot = (stot + 15) & ~(int64_t)15;  // 128-byte alignment: rows of the optimiser's global arrays are whole sectors / lines
     max_par = std::max(max_par, (int)pcnt[b]);
-    int ops = 0;
+    int ops = 0, pair = 0;
     for (int64_t i = gbeg[b]; i < gbeg[b] + gcnt[b]; ++i) {
       const int k = gates[i].kind;
       ops += (k == G_CNOT) ? 0 : (k == G_DEPOL2 ? 2 : 1);
+      pair += (k == G_RX || k == G_RY) ? 1 : 0;
     }
     max_ops = std::max(max_ops, ops);
+    max_pair = std::max(max_pair, pair);
     // expected cycles of one evaluation of the fused kernel beyond the constant energy step:
     // ~1.3 k per simulated op, ~22 per squared parameter for the optimiser update
     double ca = 1300.0, cb = 22.0, cc = 0.0;
@@ -774,6 +777,7 @@ int load_batch(vqe_t* h, int batch, const std::vector<GateRec>& gates,
   h->batch = batch;
   h->total_params = total_params;
   h->max_ops = (max_ops + 3) & ~3;
+  h->max_pair = std::min(h->max_ops, (max_pair + 3) & ~3);
   h->max_params = (max_par + 3) & ~3;
   h->h_par_begin = pbeg;
   h->h_par_count = pcnt;

@@ -179,6 +179,7 @@ struct BatchArgs {
   HamDev ham;
   NoiseCfg noise;
   int max_ops;                 // LDS capacity (ops) of this launch
+  int max_pair;                // ... of which pair ops (RX / RY gates: the only ops that can open a new register layout)
   int max_params;              // LDS capacity (cos/sin pairs)
   double rhobeg, rhoend;
   int maxfun;
@@ -270,6 +271,7 @@ struct WaveCtx {
   static constexpr bool kSplit = true;   // <= 32 rows: lanes l and l + 32 share a row
   static constexpr bool kColumns = false;
   static constexpr bool kTile = false;
+  static constexpr bool kTileWalks = false;
   // v + (the value of v in lane ^ 32)
   __device__ __forceinline__ double pair_sum(double v) const {
     const int lo = __double2loint(v), hi = __double2hiint(v);
@@ -322,31 +324,21 @@ struct WaveCtx {
   }
 };
 
-// The one-wave context of the TRAINABLE regime on the one-wave kernels (n <= 9; 129 parameters for H2O-8q): arrays in
-// global memory, row walks through an LDS transposition tile (cobyla_m0.h: walk_tiled) instead of one lane per row -
-// a lane per row touches 64 cache lines per load instruction and the CU's vector L1 looks them up one per cycle, which
-// is what bounded this regime.  Same arithmetic in the same order as WaveCtx (bit-identical trial points); padding to
-// 16 so that rows are whole 128-byte lines.  Only the kernel variant launched for such batches carries it (registers,
-// LDS for the tile).
-struct WaveRowsCtx : WaveCtx {
-  static constexpr int kPad = 16;
-  static constexpr bool kSplit = false;      // (only problems with more than 32 variables come here)
-#ifndef VQE_ROWS_TILE
-#define VQE_ROWS_TILE 1
-#endif
-  static constexpr bool kTile = VQE_ROWS_TILE != 0;
-  lds_double* tile;      // kTileDoubles + nv doubles
-  // block transfers of walk_tiled: buffer loads / stores through a descriptor of the whole array - rows beyond it read
-  // as zero and are not written (no predicates), the part of the address that is the same for all lanes sits in a
-  // scalar register (no 64-bit vector address arithmetic: the plain-C version of this walk spent 130 vector
-  // instructions per block on addresses)
+// Block transfers of cobyla_m0.h's walk_tiled for the device contexts whose matrices live in global memory: buffer
+// loads / stores through a descriptor of the whole array - rows beyond it read as zero and are not written (no
+// predicates), the part of the address that is the same for all lanes sits in a scalar register (no 64-bit vector
+// address arithmetic: the plain-C version of this walk spent 130 vector instructions per block on addresses).
+struct TileOps {
+  lds_double* tile;      // this wavefront's transposition tile (kTileDoubles)
+  lds_double* shared;    // the vector every row meets (nv doubles; one per workgroup)
   __amdgpu_buffer_rsrc_t t_rs;
   uint32_t t_voff, t_row4;      // byte offset of this lane's (row lane >> 4, entry lane & 15); bytes of four rows
   uint32_t t_ld8;
   __device__ __forceinline__ void tile_bind(const double* m, int m_rows, int ld) {
+    const uint32_t lane = threadIdx.x & 63u;
     t_rs = __builtin_amdgcn_make_buffer_rsrc((void*)m, 0, m_rows * ld * 8, 0x00020000);
     t_ld8 = (uint32_t)ld * 8u;
-    t_voff = (uint32_t)(tid >> 4) * t_ld8 + (uint32_t)(tid & 15) * 8u;
+    t_voff = (lane >> 4) * t_ld8 + (lane & 15u) * 8u;
     t_row4 = 4u * t_ld8;
   }
   __device__ __forceinline__ void tile_fetch(int jb, int i0, double (&g)[16]) const {
@@ -373,7 +365,24 @@ struct WaveRowsCtx : WaveCtx {
   __device__ __forceinline__ int popc(unsigned long long m) const { return __popcll(m); }
   __device__ __forceinline__ int ctz(unsigned long long m) const { return __builtin_ctzll(m); }
 };
-constexpr size_t kCobTileBytes = (size_t)(64 * 17) * 8;     // cby::CobylaM0::kTileDoubles doubles, + the shared vector
+constexpr size_t kCobTileBytes = (size_t)(64 * 17) * 8;     // cby::CobylaM0::kTileDoubles doubles per wavefront, + the shared vector
+
+// The one-wave context of the TRAINABLE regime on the one-wave kernels (n <= 9; 129 parameters for H2O-8q): arrays in
+// global memory, row walks through an LDS transposition tile (cobyla_m0.h: walk_tiled) instead of one lane per row -
+// a lane per row touches 64 cache lines per load instruction and the CU's vector L1 looks them up one per cycle, which
+// is what bounded this regime.  Same arithmetic in the same order as WaveCtx (bit-identical trial points); padding to
+// 16 so that rows are whole 128-byte lines.  Only the kernel variant launched for such batches carries it (registers,
+// LDS for the tile).
+struct WaveRowsCtx : WaveCtx, TileOps {
+  static constexpr int kPad = 16;
+  static constexpr bool kSplit = false;      // (only problems with more than 32 variables come here)
+#ifndef VQE_ROWS_TILE
+#define VQE_ROWS_TILE 1
+#endif
+  static constexpr bool kTile = VQE_ROWS_TILE != 0;
+  static constexpr bool kTileWalks = true;      // every row walk of tell() goes through the tile
+  __device__ __forceinline__ void tile_sync_all() const { tile_sync(); }      // the workgroup is this wavefront
+};
 __host__ __device__ inline size_t cobyla_tile_bytes(int n, int max_params) {
   return geo_one_wave(n) && max_params > 64 ? kCobTileBytes + (size_t)cby::padded(max_params, 16) * 8 : 0;
 }
@@ -382,16 +391,26 @@ __host__ __device__ inline size_t cobyla_tile_bytes(int n, int max_params) {
 // matrices in the global scratch - the trainable-path regime, ~129 parameters): every thread
 // takes a row, reductions go through LDS and s_barrier.  With one wave the row loops would run
 // several passes of a latency-bound inner loop over L2/HBM-resident matrices.
-template <int NT>
-struct BlockCtx {
+// TILE: the row walks go through per-wavefront LDS transposition tiles in the (dead) state region (walk_tiled: every
+// wavefront takes 64-row blocks) - n >= 12, where that region holds NW tiles.
+template <int NT, bool TILE = false>
+struct BlockCtx : TileOps {
   int tid;
   double* red;   // >= 12 doubles of LDS (NW sums + NW indices)
   static constexpr int nth = NT;
   static constexpr int NW = NT / 64;
-  static constexpr int kPad = 8;    // (16 - twice the loads in flight per batch - measured +5 % at 12 qubits / 202 variables)
+  static constexpr int kPad = TILE ? 16 : 8;    // (16 - twice the loads in flight per batch - measured +5 % at 12 qubits / 202 variables)
   static constexpr bool kSplit = false;
   static constexpr bool kColumns = true;   // element-wise matrix passes with the lanes along a row (cobyla_m0.h: update_simi)
-  static constexpr bool kTile = false;
+  static constexpr bool kTile = TILE;
+#ifndef VQE_BLOCK_TILE_WALKS
+#define VQE_BLOCK_TILE_WALKS 0
+#endif
+  // a thread per row in ONE pass walks its row as fast as the tile hands it over (measured, 12 qubits / 202 variables:
+  // simi . dx 7.8 -> 11.1, acceptability 21 -> 29 G cycles with tiles): only the rank-one update - whose element-wise
+  // form leaves the row norms to a later full pass - takes the tile here
+  static constexpr bool kTileWalks = VQE_BLOCK_TILE_WALKS != 0;
+  __device__ __forceinline__ void tile_sync_all() const { __syncthreads(); }
   __device__ __forceinline__ double pair_sum(double v) const { return v; }
   __device__ __forceinline__ void lockstep() const {}   // kSplit = false: a row has one owner
   __device__ __forceinline__ void sync() const { __syncthreads(); }
@@ -464,8 +483,8 @@ struct LayoutRec;
 struct Lds {
   double2* psi;     // [2^n]  (also: gate staging during compile, COBYLA matrices during tell)
   Op* ops;          // [max_ops] raw ops
-  Op* sched;        // [2*max_ops+2] scheduled ops (register path, n >= 10)
-  LayoutRec* lay;   // [max_ops+2] layouts (register path)
+  Op* sched;        // [max_ops+max_pair+2] scheduled ops (register path, n >= 10): every op + a re-layout in front of a pair op at most
+  LayoutRec* lay;   // [max_pair+2] layouts (register path)
   double2* cs;      // [max_params] (cos, sin)(theta/2)
   GroupMeta* gm;    // [n_groups]
   ClsMeta* cm;    // [n_groups] addressing records of the register energy path (n >= 10)
@@ -483,10 +502,14 @@ struct Lds {
 // upper half next to the staged gate records when they fit there, else in all of it (launch_lds
 // refuses circuits with more than 2^n ops).
 __host__ __device__ inline bool ops_fit_upper_half(int n, int max_ops) { return (size_t)max_ops <= ((size_t)1 << n) / 2; }
-__host__ __device__ inline size_t lds_bytes_base(int n, int max_ops, int max_params, int n_groups) {
+// max_pair: RX / RY gates of the longest circuit (<= max_ops).  Only a pair op whose partner mask lies outside the
+// current layout opens a new one (vqe_reg.h: schedule_ops), so the schedule has at most max_ops + max_pair records and
+// max_pair + 1 layouts - for the trainable regime at 12 qubits (203 rotations, two thirds of them RX / RY) the
+// difference to the 2 max_ops bound is what lets a second workgroup into the CU (82.8 KB -> 79.6 KB).
+__host__ __device__ inline size_t lds_bytes_base(int n, int max_ops, int max_params, int n_groups, int max_pair) {
   const int ng = n_groups > 0 ? n_groups : 1;
   size_t b = (size_t)16 << n;
-  b += n >= 10 ? (size_t)16 * (2 * max_ops + 2) + (size_t)32 * (max_ops + 2) : (size_t)16 * max_ops;
+  b += n >= 10 ? (size_t)16 * (max_ops + max_pair + 2) + (size_t)32 * (max_pair + 2) : (size_t)16 * max_ops;
   b += (size_t)16 * max_params + (size_t)16 * ng + (n >= 10 ? (size_t)48 * ng : 0);
   return b + 128 + 128 + 128 + 32 + 64 + (((size_t)2 * max_ops + 15) & ~(size_t)15);
 }
@@ -498,17 +521,17 @@ __host__ __device__ inline size_t lds_bytes_base(int n, int max_ops, int max_par
 #define VQE_RESIDENT_BUDGET (160 * 1024 / 8)
 #endif
 constexpr size_t kResidentLdsBudget = VQE_RESIDENT_BUDGET;
-__host__ __device__ inline size_t cobyla_resident_bytes(int n, int max_ops, int max_params, int n_groups) {
+__host__ __device__ inline size_t cobyla_resident_bytes(int n, int max_ops, int max_params, int n_groups, int max_pair) {
   if (n > kOneWaveMaxQubits || max_params <= 0) return 0;
   const size_t need = (cby::scratch_doubles(max_params, 8) * 8 + 15) & ~(size_t)15;
-  return lds_bytes_base(n, max_ops, max_params, n_groups) + need + 16 <= kResidentLdsBudget ? need : 0;
+  return lds_bytes_base(n, max_ops, max_params, n_groups, max_pair) + need + 16 <= kResidentLdsBudget ? need : 0;
 }
-__host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params, int n_groups) {
-  const size_t r = cobyla_resident_bytes(n, max_ops, max_params, n_groups);
-  return ((lds_bytes_base(n, max_ops, max_params, n_groups) + 15) & ~(size_t)15) + r + cobyla_tile_bytes(n, max_params);
+__host__ __device__ inline size_t lds_bytes(int n, int max_ops, int max_params, int n_groups, int max_pair) {
+  const size_t r = cobyla_resident_bytes(n, max_ops, max_params, n_groups, max_pair);
+  return ((lds_bytes_base(n, max_ops, max_params, n_groups, max_pair) + 15) & ~(size_t)15) + r + cobyla_tile_bytes(n, max_params);
 }
 
-__device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, int max_params, int n_groups) {
+__device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, int max_params, int n_groups, int max_pair) {
   const int ng = n_groups > 0 ? n_groups : 1;
   Lds l;
   l.psi = (double2*)base; base += (size_t)16 << n;
@@ -516,8 +539,8 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, in
     // raw ops: upper half of the state region (the lower half stages the gate records), or - for
     // circuits with more than 2^(n-1) ops - the whole region (gates are then read from global memory)
     l.ops = (Op*)(l.psi) + (ops_fit_upper_half(n, max_ops) ? ((size_t)1 << n) / 2 : 0);
-    l.sched = (Op*)base; base += (size_t)16 * (2 * max_ops + 2);
-    l.lay = (LayoutRec*)base; base += (size_t)32 * (max_ops + 2);
+    l.sched = (Op*)base; base += (size_t)16 * (max_ops + max_pair + 2);
+    l.lay = (LayoutRec*)base; base += (size_t)32 * (max_pair + 2);
   } else {
     l.ops = (Op*)base; base += (size_t)16 * max_ops;
     l.sched = l.ops; l.lay = (LayoutRec*)l.ops;
@@ -531,12 +554,12 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int max_ops, in
   l.meta = (int32_t*)base; base += 32;
   l.sb = (uint32_t*)base; base += 64;
   l.sidx = (uint16_t*)base;
-  l.cob = cobyla_resident_bytes(n, max_ops, max_params, n_groups)
-              ? (double*)((unsigned char*)l.psi + ((lds_bytes_base(n, max_ops, max_params, n_groups) + 15) & ~(size_t)15))
+  l.cob = cobyla_resident_bytes(n, max_ops, max_params, n_groups, max_pair)
+              ? (double*)((unsigned char*)l.psi + ((lds_bytes_base(n, max_ops, max_params, n_groups, max_pair) + 15) & ~(size_t)15))
               : nullptr;
   l.tile = cobyla_tile_bytes(n, max_params)
-               ? (double*)((unsigned char*)l.psi + ((lds_bytes_base(n, max_ops, max_params, n_groups) + 15) & ~(size_t)15) +
-                           cobyla_resident_bytes(n, max_ops, max_params, n_groups))
+               ? (double*)((unsigned char*)l.psi + ((lds_bytes_base(n, max_ops, max_params, n_groups, max_pair) + 15) & ~(size_t)15) +
+                           cobyla_resident_bytes(n, max_ops, max_params, n_groups, max_pair))
                : nullptr;
   return l;
 }
@@ -1504,7 +1527,12 @@ struct StagedCobyla {
   // which kernel variant its batch selected
   typedef cby::CobylaM0<WaveRowsCtx, false, double> CobR;
   __device__ __forceinline__ bool rows_ctx() const { return kRowsG && n > 32; }
-  typedef cby::CobylaM0<BlockCtx<Geo<N>::NT>, false, double> CobB;   // the same, whole workgroup (more rows than a wave has lanes)
+#ifndef VQE_BLOCK_TILE
+#define VQE_BLOCK_TILE 1
+#endif
+  // (tiles of the workgroup context: NW x 8.7 KB + the shared vector in the dead state region - 16 << N bytes)
+  static constexpr bool kBlockTile = VQE_BLOCK_TILE && ((size_t)16 << N) >= (Geo<N>::NT / 64) * kCobTileBytes + 4096;
+  typedef cby::CobylaM0<BlockCtx<Geo<N>::NT, kBlockTile>, false, double> CobB;   // the same, whole workgroup (more rows than a wave has lanes)
   double* red;     // LDS words of the block reductions
   bool block;      // more rows than a wave has lanes: workgroup-wide context on the global scratch
   double* gmem;    // per-problem scratch; x[] is its first array
@@ -1539,7 +1567,7 @@ struct StagedCobyla {
     red = L.red;
     block = kBlock && n > 64;
     staged = resident || (!block && (size_t)words * 8 <= ((size_t)16 << N));
-    if (block) words = (int)cby::scratch_doubles(n, BlockCtx<Geo<N>::NT>::kPad);
+    if (block) words = (int)cby::scratch_doubles(n, CobB::P);
     // arrays that stay in the global scratch use the 64-byte row layout (cobyla_m0.h: lead_dim_global)
     // (one-wave context only: with a thread per row - BlockCtx - the aligned stride measured 3.5 % slower at 12 qubits /
     // 202 variables, 4.6 % faster for the one-wave context at 8 qubits / 129 variables)
@@ -1660,7 +1688,15 @@ struct StagedCobyla {
     // BlockCtx<64> has 64 threads too, so a one-wave instantiation of the workgroup-wide update ran arg_first / all_or
     // through an UNINITIALISED `red` pointer - the "hang" recorded in round 2)
     if constexpr (!std::is_base_of<WaveCtx, decltype(cob.ctx)>::value) cob.ctx.red = red;
-    if constexpr (decltype(cob.ctx)::kTile) cob.ctx.tile = (lds_double*)tile;
+    if constexpr (decltype(cob.ctx)::kTile) {
+      if constexpr (std::is_base_of<WaveCtx, decltype(cob.ctx)>::value) {
+        cob.ctx.tile = (lds_double*)tile;
+        cob.ctx.shared = (lds_double*)tile + Cob::kTileDoubles;
+      } else {      // workgroup context: a tile per wavefront and the shared vector (<= 512 variables) in the dead state region
+        cob.ctx.tile = (lds_double*)lmem + (threadIdx.x >> 6) * Cob::kTileDoubles;
+        cob.ctx.shared = (lds_double*)lmem + (kThreads / 64) * Cob::kTileDoubles;
+      }
+    }
     // opaque copies: otherwise the array addresses bind() derives are loop invariants of the
     // evaluation loop, get hoisted out of it, spilled across the energy step (where registers
     // are scarcest) and reloaded from scratch inside every tell()
@@ -1744,7 +1780,7 @@ struct StagedCobyla {
 template <int N>
 __global__ void __launch_bounds__(Geo<N>::NT) k_lds_energy(BatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
+  const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups, A.max_pair);
   const int b = blockIdx.x;
   const bool noisy = (A.noise.p1 > 0.0 || A.noise.p2 > 0.0);
   stage_groups(A.ham, L);
@@ -1760,7 +1796,7 @@ template <int N>
 __global__ void __launch_bounds__(Geo<N>::NT) k_lds_state(BatchArgs A) {
   constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
+  const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups, A.max_pair);
   const bool noisy_state = (A.noise.p1 > 0.0 || A.noise.p2 > 0.0);
   compile_all<N>(A, 0, 0, L, -1, false, noisy_state);   // logical order for the read-out
   if (noisy_state) patch_noise<N>(A, 0, A.noise.eval_base, L, -1, false);
@@ -1794,7 +1830,7 @@ template <int N, bool WIDE = (N >= 10 && Geo<N>::NT >= 256), bool NOISY = false>
 __global__ void __launch_bounds__(Geo<N>::NT, Geo<N>::WPS) k_lds_minimize(BatchArgs A) {
   constexpr int kThreads = Geo<N>::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups);
+  const Lds L = carve(smem, N, A.max_ops, A.max_params, A.ham.n_groups, A.max_pair);
   const int b = A.order[blockIdx.x];
   const int P = A.par_count[b];
   const double* theta = A.theta + A.par_begin[b];

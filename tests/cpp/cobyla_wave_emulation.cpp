@@ -42,6 +42,7 @@ struct EmuWaveCtx {
   static constexpr bool kSplit = true;
   static constexpr bool kColumns = false;
   static constexpr bool kTile = false;   // (the device's LDS-tile walks are the plain row loops bit for bit: nothing to mirror)
+  static constexpr bool kTileWalks = false;
   void sync() const { pthread_barrier_wait(&g_bar); }
   // value of v in lane `partner(tid)`
   template <class F>

@@ -32,3 +32,6 @@ _, f, nfev = eng.batch_fetch(want_x=False)
 ev = float(nfev.sum() + B)
 print(f"12q trainable regime: {B} envs, P=202 variables, G=240, maxfun {maxfun}: kernel {ms:.1f} ms, mean nfev {nfev.mean():.1f}, "
       f"{ev / ms * 1e3 / 1e6:.3f} M evaluations/s, {B / ms * 1e3:.1f} env-steps/s, wg/CU {eng.device_info()['wg_per_cu']}")
+c = eng.debug_counters().astype(float)      # (-DVQE_STAMPS builds print the optimiser's sections to stderr)
+if c[0] > 0:
+    print(f"  per evaluation, cycles: circuit {c[1]/c[0]:.0f} energy {c[2]/c[0]:.0f} tell {c[3]/c[0]:.0f}")
