@@ -1509,6 +1509,7 @@ int vqe_hamiltonian_terms(vqe_t* h, int32_t* n_terms, int32_t* n_xgroups) {
 // The collective of the term-sharded expectation sum as a library call: one ncclAllReduce(SUM, float64, count = batch) of
 // the handle's energy array, in place, on the handle's stream.  librccl is opened lazily (no link-time dependency: a
 // process that never shards never loads it; under PyTorch the already-loaded copy of the same SONAME is reused).
+extern "C++" {      // (helpers with C++ types inside the C-ABI block)
 namespace {
 struct Id128 { char b[128]; };      // ncclUniqueId, passed by value
 struct Rccl {
@@ -1539,6 +1540,7 @@ Rccl& rccl() {
   return r;
 }
 }  // namespace
+}  // extern "C++"
 
 int vqe_comm_unique_id(void* id128) {
   if (!id128) return VQE_EINVAL;
