@@ -448,6 +448,46 @@ def test_device_cobyla_trajectory(tq, n, P, seed):
         assert nd == nh and np.abs(xd - xh).max() < 1e-8, report
 
 
+@pytest.mark.parametrize("n,P,seed", [(8, 70, 0), (9, 129, 1), (12, 70, 2), (12, 130, 3), (13, 66, 4)])
+def test_device_cobyla_trajectory_many_parameters(tq, n, P, seed):
+    """More than 64 parameters (the trainable regime): the kernel variants whose optimiser walks its matrices through
+    LDS transposition tiles - one wavefront at n <= 9 (WaveRowsCtx: every row and column walk), the whole workgroup
+    from n = 10 (BlockCtx: the rank-one update through per-wavefront tiles from n = 12, plain below).  As in
+    test_device_cobyla_trajectory the library's host COBYLA, fed with this engine's energies, must walk the same trial
+    points (1e-9) through the initial simplex and the first trust-region / geometry steps: a wrong entry of the
+    updated inverse shows in the very next trial point."""
+    rng = np.random.default_rng(1900 + seed)
+    psi0 = random_state(n, rng)
+    ham = random_hamiltonian(n, 30, rng)
+    kind, q0, q1, pidx, th = _rotations(n, P, rng)
+    eng = _engine(tq, n, psi0, ham)
+    c = tq.Circuit(kind, q0, q1, pidx, P)
+    maxfun = P + 1 + 40
+    eng.batch_set_trace(True)
+    eng.batch_load([c], [th])
+    eng.batch_run_minimize(1.0, 1e-4, maxfun)
+    xd, fd, nd = eng.batch_fetch()
+    ft, xt = eng.batch_fetch_trace(0, P)
+    eng.batch_set_trace(False)
+    nd = int(nd[0])
+    eng.set_circuit(c)
+    opt = tq.HostCobyla(th, 1.0, 1e-4, maxfun)
+    agree = 0
+    for k in range(nd):
+        x = opt.ask()
+        if x is None:
+            break
+        e = eng.energy(x)
+        if np.abs(xt[k] - x).max() > 1e-9 or abs(ft[k] - e) > 1e-10:
+            break
+        agree += 1
+        opt.tell(e)
+    print(f"n={n} P={P}: device nfev {nd}, identical trial points for the first {agree} evaluations")
+    assert nd == maxfun and agree >= P + 1 + 12, (nd, agree)
+    assert abs(eng.energy(xd) - float(fd[0])) < 1e-12
+    eng.close()
+
+
 # ---- streaming path: env-step and a 20-qubit CircuitEnv end to end --------------------------------
 def test_streaming_env_step_semantics(tq):
     """vqe_batch_run_env_step at n = 14: COBYLA sees the circuit WITHOUT the new gate, the result is rounded to
