@@ -765,7 +765,7 @@ def mps2qc_stream_aux(tq, dev):
         roof["traffic_note"] = why
     return {"workload": workload, "optimiser_steps_per_s_device": steps / (ms * 1e-3), "optimiser_steps_per_s_wall": steps / wall,
             "kernel_ms": ms, "final_loss": float(opt.loss_history[-1]),
-            "roofline": roof, "note": "one launch per gate and step, Stiefel-Adam update on the host: not tuned (DESIGN 4.5)"}
+            "roofline": roof, "note": "one launch per gate and step (replayed as a hipGraph), Stiefel-Adam update on the host between steps (DESIGN 4.5)"}
 
 
 def main():

@@ -1197,8 +1197,15 @@ extern "C" int mps2qc_fit_brickwork_stream(int device_id, int n, int G, const in
   memset(vel.data(), 0, gcount * 16);
   std::vector<double> bv(B, 10000.0);
   std::vector<int> nit(B, 0), active(B, 1);
-  std::vector<double2> h_ov(B), h_env((size_t)B * G * kMat);
   if (loss_history) memset(loss_history, 0, (size_t)B * max_iter * sizeof(double));
+  // One optimiser step is the same 3 G + 5 launches and three copies every time - only the gate values change: the
+  // sequence is captured ONCE into a hipGraph and replayed (a launch of ~10 us on a 4 MiB vector otherwise waits for
+  // the host to enqueue it; MPS2QC_STREAM_GRAPH=0: plain launches, for comparison).  The graph's copy nodes need
+  // page-locked host buffers: h_pin = [gates in | overlaps out | environments out].
+  double2 *h_pin = nullptr, *h_gin = nullptr, *h_ov = nullptr, *h_env = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  static const bool graph_on = [] { const char* e = getenv("MPS2QC_STREAM_GRAPH"); return !(e && e[0] == '0'); }();
 
   double2 *d_psi = nullptr, *d_phi = nullptr, *d_t = nullptr, *d_g = nullptr, *d_part = nullptr, *d_ov = nullptr, *d_env = nullptr;
   hipStream_t st = nullptr;
@@ -1216,26 +1223,50 @@ extern "C" int mps2qc_fit_brickwork_stream(int device_id, int n, int G, const in
   HIP_TRY(hipMalloc(&d_part, (size_t)B * (blk_vec > blk_amp ? blk_vec : blk_amp) * 16 * 16));
   HIP_TRY(hipMalloc(&d_ov, (size_t)B * 16));
   HIP_TRY(hipMalloc(&d_env, gcount * 16));
+  HIP_TRY(hipHostMalloc((void**)&h_pin, (2 * gcount + (size_t)B) * 16, hipHostMallocDefault));
+  h_gin = h_pin; h_ov = h_pin + gcount; h_env = h_ov + B;
   HIP_TRY(hipMemcpyAsync(d_t, target, tsz, hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(e0, st));
+  {
+    auto enqueue_step = [&]() -> hipError_t {
+      hipError_t e = hipMemcpyAsync(d_g, h_gin, gcount * 16, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_sf_zero_state, dim3(blk_amp, B), dim3(kSfThreads), 0, st, d_psi, dim);
+      for (int k = 0; k < G; ++k)
+        hipLaunchKernelGGL(k_sf_apply, dim3(blk_vec, B), dim3(kSfThreads), 0, st, d_psi, dim, d_g, G, k, lo[k], 0);
+      hipLaunchKernelGGL(k_sf_dot, dim3(blk_amp, B), dim3(kSfThreads), 0, st, d_t, target_shared ? 1 : 0, d_psi, dim, d_part);
+      hipLaunchKernelGGL(k_sf_reduce, dim3(B), dim3(kSfThreads), 0, st, d_part, (int)blk_amp, 1, d_ov, 1, 0);
+      hipLaunchKernelGGL(k_sf_copy, dim3(blk_amp, B), dim3(kSfThreads), 0, st, d_phi, d_t, dim, target_shared ? 1 : 0);
+      for (int k = G - 1; k >= 0; --k) {
+        hipLaunchKernelGGL(k_sf_back, dim3(blk_vec, B), dim3(kSfThreads), 0, st, d_psi, d_phi, dim, d_g, G, k, lo[k], d_part);
+        hipLaunchKernelGGL(k_sf_reduce, dim3(B), dim3(kSfThreads), 0, st, d_part, (int)blk_vec, 16, d_env, G * kMat, k);
+      }
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      if ((e = hipMemcpyAsync(h_ov, d_ov, (size_t)B * 16, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+      return hipMemcpyAsync(h_env, d_env, gcount * 16, hipMemcpyDeviceToHost, st);
+    };
+    if (graph_on) {
+      // (the target copy above must have been issued before the capture begins; a failed capture falls back to plain launches)
+      HIP_TRY(hipStreamSynchronize(st));
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const hipError_t e = enqueue_step();
+        hipGraph_t g = nullptr;
+        const hipError_t e2 = hipStreamEndCapture(st, &g);
+        if (e == hipSuccess && e2 == hipSuccess && g && hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0) == hipSuccess) graph = g;
+        else {
+          if (g) (void)hipGraphDestroy(g);
+          gexec = nullptr;
+          (void)hipGetLastError();
+        }
+      } else (void)hipGetLastError();
+    }
   for (int it = 0; it < max_iter; ++it) {
     int any = 0;
     for (int b = 0; b < B; ++b) any |= active[b];
     if (!any) break;
-    HIP_TRY(hipMemcpyAsync(d_g, U.data(), gcount * 16, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_sf_zero_state, dim3(blk_amp, B), dim3(kSfThreads), 0, st, d_psi, dim);
-    for (int k = 0; k < G; ++k)
-      hipLaunchKernelGGL(k_sf_apply, dim3(blk_vec, B), dim3(kSfThreads), 0, st, d_psi, dim, d_g, G, k, lo[k], 0);
-    hipLaunchKernelGGL(k_sf_dot, dim3(blk_amp, B), dim3(kSfThreads), 0, st, d_t, target_shared ? 1 : 0, d_psi, dim, d_part);
-    hipLaunchKernelGGL(k_sf_reduce, dim3(B), dim3(kSfThreads), 0, st, d_part, (int)blk_amp, 1, d_ov, 1, 0);
-    hipLaunchKernelGGL(k_sf_copy, dim3(blk_amp, B), dim3(kSfThreads), 0, st, d_phi, d_t, dim, target_shared ? 1 : 0);
-    for (int k = G - 1; k >= 0; --k) {
-      hipLaunchKernelGGL(k_sf_back, dim3(blk_vec, B), dim3(kSfThreads), 0, st, d_psi, d_phi, dim, d_g, G, k, lo[k], d_part);
-      hipLaunchKernelGGL(k_sf_reduce, dim3(B), dim3(kSfThreads), 0, st, d_part, (int)blk_vec, 16, d_env, G * kMat, k);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_ov.data(), d_ov, (size_t)B * 16, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h_env.data(), d_env, gcount * 16, hipMemcpyDeviceToHost, st));
+    memcpy(h_gin, U.data(), gcount * 16);
+    if (gexec) HIP_TRY(hipGraphLaunch(gexec, st));
+    else HIP_TRY(enqueue_step());
     HIP_TRY(hipStreamSynchronize(st));
     const double t = jit_frozen ? 1.0 : (double)(it + 1);
     const double lr_t = lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t));      // (stiefel_opt.py:333-335)
@@ -1267,6 +1298,7 @@ extern "C" int mps2qc_fit_brickwork_stream(int device_id, int n, int G, const in
       if (val < tol || dsum / G < param_tol) active[b] = 0;
     }
   }
+  }
   HIP_TRY(hipEventRecord(e1, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -1275,11 +1307,14 @@ extern "C" int mps2qc_fit_brickwork_stream(int device_id, int n, int G, const in
   if (final_gates) memcpy(final_gates, U.data(), gcount * 16);
   if (best_val) memcpy(best_val, bv.data(), B * sizeof(double));
   if (n_iter) for (int b = 0; b < B; ++b) n_iter[b] = nit[b];
-  if (last_envs) memcpy(last_envs, h_env.data(), gcount * 16);
-  if (last_overlap) memcpy(last_overlap, h_ov.data(), (size_t)B * 16);
+  if (last_envs) memcpy(last_envs, h_env, gcount * 16);
+  if (last_overlap) memcpy(last_overlap, h_ov, (size_t)B * 16);
 
 done:
   for (void* p : {(void*)d_psi, (void*)d_phi, (void*)d_t, (void*)d_g, (void*)d_part, (void*)d_ov, (void*)d_env}) (void)hipFree(p);
+  if (gexec) (void)hipGraphExecDestroy(gexec);
+  if (graph) (void)hipGraphDestroy(graph);
+  if (h_pin) (void)hipHostFree(h_pin);
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   if (st) (void)hipStreamDestroy(st);
