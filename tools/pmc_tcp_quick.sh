@@ -1,5 +1,6 @@
 #!/bin/bash
-# quick vector-memory counters (texture addresser / L1) of k_lds_minimize in one bench object; VQE_HIP_LIB etc. pass through
+# quick vector-memory counters (texture addresser, vector L1, L2: busy / stall cycles, accesses, read latency) of
+# k_lds_minimize in one bench object, five separate passes; VQE_HIP_LIB etc. pass through
 #   tools/pmc_tcp_quick.sh <tag> <bench --only key>
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -8,7 +9,7 @@ KEY=${2:-trainable8}
 rm -rf $OUT; mkdir -p $OUT
 CMD="python3 $REPO/bench.py --only $KEY"
 i=0
-for set in "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCC_EA_RDREQ_sum TCC_TAG_STALL_sum TCC_BUSY_avr GRBM_GUI_ACTIVE"; do
+for set in "TA_TA_BUSY_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCC_EA_RDREQ_sum TCC_TAG_STALL_sum TCC_BUSY_avr GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- $CMD > $OUT/p$i.log 2>&1 || echo "pass $i failed: $(tail -2 $OUT/p$i.log)"
 done
