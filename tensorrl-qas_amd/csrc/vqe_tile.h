@@ -263,7 +263,7 @@ struct EGroupRec {            // 4 + kEPairs dwords
   uint32_t cx16;              // tile coordinates of the X mask, as a byte offset (<< 4); 0: the diagonal group
   uint32_t hb;                // highest set bit of the coordinates
   int32_t nt;                 // its terms: the next nt records of eterm (groups and terms are stored in the order they run)
-  uint32_t im;                // some weight has an imaginary part (then wi[] is read as well)
+  uint32_t im;                // 1: some weight has an imaginary part (then wi[] is read as well); 2: a half group (hb, u16: see the planner)
   uint32_t u16[kEPairs];      // byte offset of pair k of a thread: insert0(k * kThreads, hb) << 4
 };
 struct ETermRec {             // 4 + 2 kEPairs dwords
@@ -359,6 +359,28 @@ __global__ void k_t_plan_energy(BatchArgs A, int n_terms, const uint32_t* gxp, c
             ++in_class;
           }
           if (!c) G.u16[cls >> 1] |= (uint32_t)in_class << (16 * (cls & 1));     // (u16 is zero for the diagonal group)
+        }
+        // A pair group of TWO real terms of equal magnitude (XX + YY of a bond: the hopping part of a number-conserving
+        // operator) has D(p) = w1 s1(p) + w2 s2(p) = 2 w1 s1(p) on the half space parity(p & (z1 ^ z2)) = const and
+        // EXACTLY zero on the other half: the kernel then visits only the pairs of that half - two per thread instead
+        // of four, one signed weight instead of two (the streaming path's form of the unit path of the LDS kernels).
+        // Needs a tile coordinate besides the pair bit in z1 ^ z2 to enumerate the half space with.
+        if (c && G.nt == 2 && !G.im) {
+          ETermRec& E1 = eterm[(size_t)b * n_terms + rpos - 2];
+          const ETermRec& E2 = eterm[(size_t)b * n_terms + rpos - 1];
+          const uint32_t czd = (E1.cz ^ E2.cz) & ~(1u << hb);
+          if ((E1.wr == E2.wr || E1.wr == -E2.wr) && E1.wr != 0.0 && czd != 0u) {
+            const int q = 31 - __clz((int)czd);
+            const int lo = q < hb ? q : hb, hi = q < hb ? hb : q;
+            G.im = 2u;
+            G.hb = (uint32_t)hb | ((uint32_t)q << 8) | ((E1.wr == E2.wr ? 0u : 1u) << 16);
+            static_assert(kEPairs >= kEPairs / 2 + 2, "half groups: kEPairs / 2 pair offsets and two masks in u16");
+            for (int j = 0; j < kEPairs / 2; ++j)      // pair j of a thread: index bits 8.., zeros inserted at the two holes
+              G.u16[j] = insert0(insert0((uint32_t)j * kThreads, lo), hi) << 4;
+            G.u16[kEPairs / 2] = E1.cz ^ E2.cz;
+            G.u16[kEPairs / 2 + 1] = E1.tz ^ E2.tz;
+            E1.wr = 2.0 * E1.wr;      // D on the half space (the pair factor 2 is in wr already)
+          }
         }
         egrp[(size_t)b * ng + pos] = G;
         ord[pos++] = g;
@@ -660,6 +682,29 @@ __global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double
         for (int k = 0; k < NE; ++k) acc = fma(a[k].x * a[k].x + a[k].y * a[k].y, d[k], acc);
         return;
       }
+      if (B.g.im == 2u) {       // two equal-magnitude real terms: only the half space on which their sum does not vanish
+        const int hb = (int)(B.g.hb & 0xffu), q = (int)((B.g.hb >> 8) & 0xffu);
+        constexpr int NPH = NPR / 2;
+        const uint32_t czd = B.g.u16[NPH];
+        // pairs with parity(e & czd) == v carry D = 2 w1 s1; the others exactly zero
+        const uint32_t v = ((B.g.hb >> 16) ^ (uint32_t)__builtin_popcount(pt & B.g.u16[NPH + 1])) & 1u;
+        const int lo = q < hb ? q : hb, hi = q < hb ? hb : q;
+        const uint32_t e0t = insert0(insert0(tid, lo), hi);
+        double2 ha[NPH], hbv[NPH];
+        uint32_t he[NPH];
+#pragma unroll
+        for (int k = 0; k < NPH; ++k) {
+          const uint32_t e0 = k ? e0t | (B.g.u16[k] >> 4) : e0t;
+          he[k] = e0 | ((((uint32_t)__builtin_popcount(e0 & czd) ^ v) & 1u) << q);
+          hbv[k] = lds_load_d2(tile_b, he[k] << 4);
+          ha[k] = lds_load_d2(tile_b, (he[k] << 4) ^ cx16);
+        }
+        const ETermRec& r = B.t[0];
+#pragma unroll
+        for (int k = 0; k < NPH; ++k)
+          acc = fma(ha[k].x * hbv[k].x + ha[k].y * hbv[k].y, signed_w(r.wr, he[k], r.cz, r.tz), acc);
+        return;
+      }
       const uint32_t a0 = insert0(tid, (int)B.g.hb) << 4;
       // both members of the thread's pairs: requested before the sign sums, consumed after them
       double2 pa[NPR], pb[NPR];
@@ -683,7 +728,7 @@ __global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double
       for (int t = kBlobTerms; t < nt; ++t) term(T[cur + t]);
 #pragma unroll
       for (int k = 0; k < NPR; ++k) acc = fma(pa[k].x * pb[k].x + pa[k].y * pb[k].y, dr[k], acc);
-      if (B.g.im) {            // imaginary parts of the weights (odd number of Y factors): rare
+      if (B.g.im & 1u) {       // imaginary parts of the weights (odd number of Y factors): rare
         double di[NPR];
 #pragma unroll
         for (int k = 0; k < NPR; ++k) di[k] = 0.0;
