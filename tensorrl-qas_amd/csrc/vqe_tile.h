@@ -33,7 +33,18 @@ namespace vqe {
 #define VQE_TILE_BITS 11
 #endif
 constexpr int kTileBits = VQE_TILE_BITS;
-constexpr int kTileLow = 4;
+#ifndef VQE_TILE_LOW
+#define VQE_TILE_LOW 3
+#endif
+#ifndef VQE_ETILE_LOW
+#define VQE_ETILE_LOW 4
+#endif
+// e_0 .. e_{kTileLow-1} are in every tile: aligned runs of 16 << kTileLow bytes.  Circuit passes: 128-byte runs (one
+// cache line) and EIGHT independent masks per pass - fewer passes: 49.0 -> 50.6 k evaluations/s on the 20-qubit bench
+// workload against 256-byte runs and seven masks (512-byte runs / six masks: 47.6 k; 64-byte runs / nine: 50.3 k).  The
+// reduction keeps 256-byte runs (its three passes do not become two with eight masks, and it only reads).
+constexpr int kTileLow = VQE_TILE_LOW;
+constexpr int kETileLow = VQE_ETILE_LOW;
 constexpr int kTileAmps = 1 << kTileBits;
 constexpr int kTileFree = kTileBits - kTileLow;   // independent masks a pass can take
 constexpr int kMaxEnergyPasses = 32;
@@ -46,7 +57,7 @@ constexpr int kMaxEnergyPasses = 32;
 #endif
 constexpr int kETileBits = VQE_ETILE_BITS;
 constexpr int kETileAmps = 1 << kETileBits;
-constexpr int kETileFree = kETileBits - kTileLow;
+constexpr int kETileFree = kETileBits - kETileLow;
 
 struct TilePass {
   uint32_t basis[kTileBits];  // fully reduced (every vector has a pivot = highest bit that no other vector has), ascending pivots:
@@ -294,8 +305,8 @@ __global__ void k_t_plan_energy(BatchArgs A, int n_terms, const uint32_t* gxp, c
     P[k].basis[dims[k]] = r; piv[k][dims[k]] = p; ++dims[k];
   };
   auto open = [&]() {
-    for (int i = 0; i < kTileLow; ++i) { P[np].basis[i] = 1u << i; piv[np][i] = i; }
-    dims[np] = kTileLow;
+    for (int i = 0; i < kETileLow; ++i) { P[np].basis[i] = 1u << i; piv[np][i] = i; }
+    dims[np] = kETileLow;
     return np++;
   };
   for (int g = 0; g < ng; ++g) {
@@ -318,7 +329,7 @@ __global__ void k_t_plan_energy(BatchArgs A, int n_terms, const uint32_t* gxp, c
   TermRec* rec = trec + (size_t)b * n_terms;
   int pos = 0, rpos = 0;
   for (int k = 0; k < np; ++k) {
-    for (int q = kTileLow; q < A.n && dims[k] < kETileBits; ++q) { const uint32_t r = reduce(k, 1u << q); if (r) add(k, r); }
+    for (int q = kETileLow; q < A.n && dims[k] < kETileBits; ++q) { const uint32_t r = reduce(k, 1u << q); if (r) add(k, r); }
     for (int i = 1; i < kETileBits; ++i)
       for (int j = i; j > 0 && piv[k][j - 1] > piv[k][j]; --j) {
         const uint32_t tv = P[k].basis[j]; P[k].basis[j] = P[k].basis[j - 1]; P[k].basis[j - 1] = tv;
@@ -400,18 +411,18 @@ __device__ __forceinline__ uint32_t tile_origin(uint32_t tile, uint32_t pivmask,
   return p;
 }
 // offset of tile element t = tid + 256 k: low kTileLow bits are address bits, the other 8 coordinates select basis vectors
-template <int BITS>
+template <int LOW, int BITS>
 __device__ __forceinline__ uint32_t tile_lane_offset(const uint32_t (&basis)[BITS], uint32_t tid) {
-  uint32_t x = tid & ((1u << kTileLow) - 1u);
+  uint32_t x = tid & ((1u << LOW) - 1u);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) if ((tid >> (kTileLow + i)) & 1u) x ^= basis[kTileLow + i];
+  for (int i = 0; i < 8 - LOW; ++i) if ((tid >> (LOW + i)) & 1u) x ^= basis[LOW + i];
   return x;
 }
 template <int BITS>
 __device__ __forceinline__ uint32_t tile_k_offset(const uint32_t (&basis)[BITS], int k) {
   uint32_t x = 0;
 #pragma unroll
-  for (int i = 0; i < BITS - kTileLow - 4; ++i) if ((k >> i) & 1) x ^= basis[kTileLow + 4 + i];
+  for (int i = 0; i < BITS - 8; ++i) if ((k >> i) & 1) x ^= basis[8 + i];
   return x;
 }
 
@@ -485,7 +496,7 @@ __global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states
   const uint32_t pivmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.pivmask);
   const size_t dim = (size_t)1 << A.n;
   const uint32_t tid = threadIdx.x;
-  const uint32_t lane_off = tile_lane_offset(basis, tid);
+  const uint32_t lane_off = tile_lane_offset<kTileLow>(basis, tid);
   double2* psi = states + (size_t)b * dim;
   const double2* src = pass == 0 ? A.init : psi;      // the first pass starts from the shared initial state
   const int o_begin = __builtin_amdgcn_readfirstlane(P.begin), o_end = __builtin_amdgcn_readfirstlane(P.end);
@@ -610,7 +621,7 @@ __global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double
   const uint32_t pivmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.pivmask);
   const size_t dim = (size_t)1 << A.n;
   const uint32_t tid = threadIdx.x;
-  const uint32_t lane_off = tile_lane_offset(basis, tid);
+  const uint32_t lane_off = tile_lane_offset<kETileLow>(basis, tid);
   const double2* psi = states + (size_t)b * dim;
   constexpr int NE = kETileAmps / kThreads;           // elements per thread
   constexpr int NPR = kEPairs;      // pairs per thread
