@@ -284,6 +284,47 @@ def test_streaming_groups_with_many_terms(tq):
     assert abs(eng.energy(th) - vo.energy_pauli(psi, *ham_c)) < E_TOL
 
 
+@pytest.mark.parametrize("n,seed", [(14, 0), (16, 1)])
+def test_streaming_half_groups(tq, n, seed):
+    """Tile kernels: X-mask groups of exactly two real terms of equal magnitude (the XX + YY of a hopping term) are
+    evaluated on the half space where their sum does not vanish (half groups).  Here: bonds between
+    arbitrary qubit pairs with a Z string in between (Jordan-Wigner hopping), weights of either sign and both relative
+    signs of the two terms, next to pairs of UNEQUAL magnitude, single-term groups and a diagonal part - which take the
+    general path - behind circuits whose CNOTs move every mask through the layout."""
+    rng = np.random.default_rng(4400 + seed)
+    psi0 = random_state(n, rng)
+    terms = {}
+
+    def add(x, z, w):
+        terms[(x, z)] = terms.get((x, z), 0.0) + w
+
+    pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]
+    for i in rng.choice(len(pairs), 14, replace=False):
+        a, b = pairs[i]
+        x = (1 << a) | (1 << b)
+        zs = sum(1 << k for k in range(a + 1, b))
+        w = float(rng.normal())
+        rel = [1.0, -1.0, 0.5, 1.0][int(rng.integers(4))]            # equal, opposite, unequal magnitude
+        add(x, zs, w)                                                # X Z..Z X
+        add(x, zs | x, rel * w)                                      # Y Z..Z Y  (two Y: real weight)
+    for q in range(n):
+        add(0, 1 << q, float(rng.normal()))
+    add(0b1011, 0, 0.3)                                              # a single-term group
+    keys = sorted(terms)
+    ham = (np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64),
+           np.array([terms[k] for k in keys]))
+    eng = _engine(tq, n, psi0, ham)
+    for G in (6, 40):
+        kind, q0, q1, pidx, th = random_gates(n, G, rng, p_cnot=0.6)
+        eng.set_circuit(tq.Circuit(kind, q0, q1, pidx, th.size))
+        ths = th[None, :] + rng.normal(size=(3, th.size))
+        got = eng.energy_batch(ths)
+        for i in range(3):
+            ref = vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, ths[i]), *ham)
+            assert abs(got[i] - ref) < E_TOL, (n, G, i, got[i] - ref)
+    eng.close()
+
+
 def test_streaming_fallback_kernels(tq, tmp_path):
     """VQE_STREAM_TILED=0 (read once per process) selects the one-sweep-per-four-ops kernels that also serve
     Hamiltonian shards too large for the tile planner: same energies as the oracle."""
