@@ -82,6 +82,9 @@ def _cpu_facts():
     return model, blas
 
 
+ALL_CPUS = None      # the CPU mask of the process before main() bound its host threads
+
+
 def cpu_baseline(tq, ham, psi0, batch, G, n_steps, maxfun, one_thread_evals=400):
     """Reference algorithm on the host cores for a bounded sample of the same workload:
     C restatement of the qulacs gate sweeps (oracle/vqe_oracle.c) + the literal dense
@@ -95,6 +98,9 @@ def cpu_baseline(tq, ham, psi0, batch, G, n_steps, maxfun, one_thread_evals=400)
     import vqe_oracle as vo
     from scipy.optimize import minimize
     from threadpoolctl import threadpool_limits
+    # the CPU reference gets every core of the host: main() confined this thread to one L3 domain for the GPU's sake
+    if ALL_CPUS is not None and hasattr(os, "sched_setaffinity"):
+        os.sched_setaffinity(0, ALL_CPUS)
     n = N_QUBITS
     idx = np.arange(2 ** n)
     dense = np.zeros((2 ** n, 2 ** n), np.complex128)
@@ -820,6 +826,19 @@ def main():
     if args.selftest_launch:
         return launch_selftest(args, rank, world)
 
+    # Host threads on ONE L3 domain, before anything creates the HIP runtime's helper threads (tensorrl_qas_amd/affinity.py:
+    # a loop of ~10 us launches otherwise runs up to 5 x slower on the pool's two-socket hosts, from process to process;
+    # VQE_CPU_BIND=0 switches it off).  The BLAS pool of the CPU baseline is started first, with the full CPU mask.
+    global ALL_CPUS
+    if hasattr(os, "sched_getaffinity"):
+        ALL_CPUS = set(os.sched_getaffinity(0))
+        _ = np.ones((512, 512)) @ np.ones((512, 512))
+    import importlib.util
+    _spec = importlib.util.spec_from_file_location("vqe_affinity", os.path.join(ROOT, "tensorrl-qas_amd", "affinity.py"))
+    _aff = importlib.util.module_from_spec(_spec)
+    _spec.loader.exec_module(_aff)
+    cpu_bind = _aff.bind_host_threads(local)
+
     import torch
     import torch.distributed as dist
     import tensorrl_qas_amd as tq
@@ -970,7 +989,9 @@ def main():
             "config": {"workload": workload,
                        "n_qubits": n, "pauli_terms": T, "x_groups": Tx, "gates": G, "envs_per_gpu": B,
                        "cobyla": {"rhobeg": 1.0, "rhoend": 1e-4, "maxfun": args.maxfun},
-                       "mean_nfev": mean_nfev, "parallelism": f"env-replicas x{world}"},
+                       "mean_nfev": mean_nfev, "parallelism": f"env-replicas x{world}",
+                       "host_threads": ("%d logical CPUs of one L3 domain, first %d (tensorrl_qas_amd.bind_host_threads; the CPU baseline "
+                                        "runs on all %d)" % (len(cpu_bind), min(cpu_bind), len(ALL_CPUS or ()))) if cpu_bind else "unbound"},
             "evals_per_s": world * evals_per_launch / (k_ms * 1e-3),
             "energy_checksum": float(np.sum(f)),
             "roofline": roof,

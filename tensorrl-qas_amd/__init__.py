@@ -6,5 +6,6 @@ mirrors the reference's environment interface.  There is no CPU fallback."""
 from ._lib import VQEError, LIB_PATH  # noqa: F401
 from .engine import VQEEngine, HostCobyla, Circuit  # noqa: F401
 from . import hamiltonian, qasm, circuits  # noqa: F401
+from .affinity import bind_host_threads  # noqa: F401
 
-__all__ = ["VQEEngine", "HostCobyla", "Circuit", "VQEError", "hamiltonian", "qasm", "circuits"]
+__all__ = ["VQEEngine", "HostCobyla", "Circuit", "VQEError", "hamiltonian", "qasm", "circuits", "bind_host_threads"]

@@ -293,3 +293,30 @@ def test_exact_channel_block_fusion_on_the_host():
         assert np.abs(got - ref).max() < 1e-12, (n, np.abs(got - ref).max())
         changes = 1 + sum(1 for i in range(1, kind.size) if {q0[i], max(q1[i], q0[i])} - {q0[i - 1], max(q1[i - 1], q0[i - 1])})
         assert 1 <= nb.value <= changes
+
+
+def test_host_thread_binding_helper(monkeypatch):
+    """tensorrl_qas_amd.bind_host_threads: the L3 domains partition the CPUs this thread may use; the binding confines
+    the calling thread to one of them (nothing to do on a host with a single domain), rank r of a node takes another
+    domain than rank 0 when there are several, and VQE_CPU_BIND=0 switches it off.  The test restores the mask."""
+    import os
+    from tensorrl_qas_amd import affinity
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no sched_getaffinity on this platform")
+    before = set(os.sched_getaffinity(0))
+    try:
+        doms = affinity.l3_domains()
+        assert doms == [] or sorted(c for d in doms for c in d) == sorted(before)
+        monkeypatch.setenv("VQE_CPU_BIND", "0")
+        assert affinity.bind_host_threads(0) is None and set(os.sched_getaffinity(0)) == before
+        monkeypatch.setenv("VQE_CPU_BIND", "1")
+        got = affinity.bind_host_threads(0)
+        if len(doms) <= 1:
+            assert got is None and set(os.sched_getaffinity(0)) == before
+        else:
+            assert got == doms[0] and set(os.sched_getaffinity(0)) == set(doms[0])
+            os.sched_setaffinity(0, before)
+            other = affinity.bind_host_threads(1, ranks_per_node=len(doms))
+            assert other == doms[1]
+    finally:
+        os.sched_setaffinity(0, before)

@@ -22,6 +22,14 @@ if "engine" in case:
     c = tq.Circuit(kind, q0, q1, pidx, 4)
     eng.batch_load([c] * 64, [rng.normal(size=4)] * 64); eng.batch_run_minimize(1.0, 1e-4, 50); eng.sync()
     keep.append(eng)
+if "many" in case:      # several engines, each with a stream of its own
+    for i in range(6):
+        e8 = tq.VQEEngine(8)
+        hh8, _ = tq.hamiltonian.heisenberg(8)
+        e8.set_hamiltonian(hh8.xmask, hh8.zmask, hh8.coeff)
+        c8 = tq.Circuit(np.array([1, 2], np.int32), np.array([0, 1], np.int32), np.array([-1, -1], np.int32), np.array([0, 1], np.int32), 2)
+        e8.batch_load([c8] * 8, [np.zeros(2)] * 8); e8.batch_run_minimize(1.0, 1e-4, 20); e8.sync()
+        keep.append(e8)
 if "big" in case:
     e20 = tq.VQEEngine(20)
     hh, _ = tq.hamiltonian.heisenberg(20)
