@@ -29,6 +29,7 @@ struct StreamWork {
   uint32_t* tzp = nullptr;    size_t tzp_cap = 0;      // [batch][n_terms] physical Z masks
   double* tsg = nullptr;      size_t tsg_cap = 0;      // [batch][n_terms] (-1)^{z.c}
   double* partial = nullptr;  size_t partial_cap = 0;  // [batch][blocks]
+  bool plan_fused = false;    // the energy plan's pass 0 is the tile of the last circuit pass (vqe_tile.h: fused pass)
   // LDS-tiled kernels (vqe_tile.h)
   void* passes = nullptr;     size_t passes_cap = 0;   // TilePass [batch][max_pass]
   void* opc = nullptr;        size_t opc_cap = 0;      // OpCoord [batch][max_ops]
@@ -465,37 +466,76 @@ inline int stream_evaluate(StreamWork& sw, const BatchArgs& A, int n_terms, hipS
     }
     const int tiles_rank = (int)(dim >> kETileBits) / world;     // tiles of the Pauli-term reduction in this rank's slice
     const int e_blocks = (tiles_rank + kTilesPerBlock - 1) / kTilesPerBlock;     // k_t_energy: one partial per workgroup
-    SW_TRY(sw_reserve(sw.partial, sw.partial_cap, (size_t)B * e_pass * e_blocks));
+    const int o_blocks = (tiles + kOpsTilesPerBlock - 1) / kOpsTilesPerBlock;
+    // partial sums of a stream: [e_pass][e_blocks] of k_t_energy, then [o_blocks] of the fused pass (the pair groups that
+    // close inside the tile of the last circuit pass are evaluated there, before the final state leaves the LDS)
+    const int p_stride = e_pass * e_blocks + o_blocks;
+    SW_TRY(sw_reserve(sw.partial, sw.partial_cap, (size_t)B * p_stride));
+    static const bool fuse_on = [] { const char* e = getenv("VQE_STREAM_FUSE"); return !(e && e[0] == '0'); }();   // A/B knob
+    auto plan_energy = [&](bool with_last_pass) {
+      hipLaunchKernelGGL(k_t_plan_energy, dim3((B + 63) / 64), dim3(64), 0, st, A, n_terms, sw.gxp, sw.tzp, sw.tsg,
+                         (ETilePass*)sw.epasses, sw.npass + B, sw.eorder, sw.gcx, sw.grec, (TermRec*)sw.trec,
+                         sw.eorder + (size_t)B * ng, (EGroupRec*)sw.egrp, (ETermRec*)sw.eterm, sw.ewi,
+                         with_last_pass ? (const TilePass*)sw.passes : (const TilePass*)nullptr, (const int32_t*)sw.npass, max_pass);
+      sw.plan_fused = with_last_pass;
+    };
+    const int m_terms = std::max(nt, ng);
+    bool fused = false;
+    bool energy_ready = sw.plan_energy_ok;      // (a noisy run plans anew in every call: the flags stay false)
     if (want_circuit) {
       hipLaunchKernelGGL(k_s_sincos, dim3((A.max_params + 63) / 64, B), dim3(64), 0, st, A, sw.cs);
       if (!sw.plan_ops_ok) {
         hipLaunchKernelGGL(k_s_compile, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.masks, sw.meta, eval_id);
+        const bool with_groups = want_energy && fuse_on;      // (the Pauli masks follow the layout the circuit leaves: sw.masks)
+        if (with_groups)
+          hipLaunchKernelGGL(k_s_terms, dim3((m_terms + 63) / 64, B), dim3(64), 0, st, A, sw.masks, sw.meta, n_terms, sw.gxp,
+                             sw.tzp, sw.tsg);
         hipLaunchKernelGGL(k_t_plan_ops, dim3((B + 63) / 64), dim3(64), 0, st, A, sw.ops, sw.meta, (TilePass*)sw.passes,
-                           (OpCoord*)sw.opc, (ChunkRec*)sw.chunks, sw.npass, max_pass);
+                           (OpCoord*)sw.opc, (ChunkRec*)sw.chunks, sw.npass, max_pass,
+                           with_groups ? (const uint32_t*)sw.gxp : (const uint32_t*)nullptr);
         sw.plan_ops_ok = !noisy;
-        sw.plan_energy_ok = false;       // the Pauli masks follow the layout the circuit leaves
+        sw.plan_energy_ok = false;
+        energy_ready = false;
+        if (with_groups) {
+          plan_energy(true);
+          sw.plan_energy_ok = !noisy;
+          energy_ready = true;
+        }
       }
+      if (want_energy && (!energy_ready || sw.plan_fused != fuse_on)) {      // (an op plan cached from a circuit-only call, or an
+        hipLaunchKernelGGL(k_s_terms, dim3((m_terms + 63) / 64, B), dim3(64), 0, st, A, sw.masks, sw.meta, n_terms, sw.gxp,   // energy-only plan)
+                           sw.tzp, sw.tsg);
+        plan_energy(fuse_on);
+        sw.plan_energy_ok = !noisy && sw.plan_ops_ok;
+        energy_ready = true;
+      }
+      fused = want_energy && sw.plan_fused;
       hipLaunchKernelGGL(k_t_cs_ops, dim3((A.max_ops + 63) / 64, B), dim3(64), 0, st, A, sw.ops, sw.meta, sw.cs, sw.csop);
-      const int o_blocks = (tiles + kOpsTilesPerBlock - 1) / kOpsTilesPerBlock;
-      for (int p = 0; p < max_pass; ++p)
-        hipLaunchKernelGGL(k_t_ops, dim3((unsigned)o_blocks, B), dim3(kThreads), 0, st, A, sw.states,
-                           (const ChunkRec*)sw.chunks, (const double2*)sw.csop, (const TilePass*)sw.passes, sw.npass, p,
-                           max_pass, tiles);
+      FusedEnergy F{fused ? sw.partial : nullptr, (const ETilePass*)sw.epasses, (const EGroupRec*)sw.egrp, (const ETermRec*)sw.eterm,
+                    (const double*)sw.ewi, n_terms, tiles_rank, p_stride, e_pass * e_blocks};
+      for (int p = 0; p < max_pass; ++p) {
+        if (p + 1 < max_pass || !fused)      // (a stream's last pass is pass max_pass - 1 at the latest)
+          hipLaunchKernelGGL(k_t_ops<false>, dim3((unsigned)o_blocks, B), dim3(kThreads), 0, st, A, sw.states,
+                             (const ChunkRec*)sw.chunks, (const double2*)sw.csop, (const TilePass*)sw.passes, sw.npass, p,
+                             max_pass, tiles, F);
+        if (fused)
+          hipLaunchKernelGGL(k_t_ops<true>, dim3((unsigned)o_blocks, B), dim3(kThreads), 0, st, A, sw.states,
+                             (const ChunkRec*)sw.chunks, (const double2*)sw.csop, (const TilePass*)sw.passes, sw.npass, p,
+                             max_pass, tiles, F);
+      }
     }
     if (want_energy) {
-      if (!sw.plan_energy_ok) {
-        const int m = std::max(nt, ng);
-        hipLaunchKernelGGL(k_s_terms, dim3((m + 63) / 64, B), dim3(64), 0, st, A, sw.masks, sw.meta, n_terms,
-                           sw.gxp, sw.tzp, sw.tsg);
-        hipLaunchKernelGGL(k_t_plan_energy, dim3((B + 63) / 64), dim3(64), 0, st, A, n_terms, sw.gxp, sw.tzp, sw.tsg,
-                           (ETilePass*)sw.epasses, sw.npass + B, sw.eorder, sw.gcx, sw.grec, (TermRec*)sw.trec,
-                           sw.eorder + (size_t)B * ng, (EGroupRec*)sw.egrp, (ETermRec*)sw.eterm, sw.ewi);
+      if (!energy_ready || (!fused && sw.plan_fused)) {      // (energy of the resident states without their circuits: a plan whose
+        hipLaunchKernelGGL(k_s_terms, dim3((m_terms + 63) / 64, B), dim3(64), 0, st, A, sw.masks, sw.meta, n_terms, sw.gxp,   // pass 0 is a tile of k_t_energy's own)
+                           sw.tzp, sw.tsg);
+        plan_energy(false);
         sw.plan_energy_ok = !noisy && sw.plan_ops_ok;
       }
+      if (!fused) SW_TRY(hipMemsetAsync(sw.partial, 0, (size_t)B * p_stride * sizeof(double), st));     // (the fused pass's slots)
       hipLaunchKernelGGL(k_t_energy, dim3((unsigned)e_blocks, B, e_pass), dim3(kThreads), 0, st, A, sw.states, n_terms,
                          (const ETilePass*)sw.epasses, sw.npass + B, (const EGroupRec*)sw.egrp, (const ETermRec*)sw.eterm,
-                         sw.ewi, sw.partial, tiles_rank);
-      hipLaunchKernelGGL(k_s_reduce, dim3(B), dim3(kThreads), 0, st, sw.partial, e_pass * e_blocks, A.fout, A.noise,
+                         sw.ewi, sw.partial, tiles_rank, p_stride, fused ? 1 : 0);
+      hipLaunchKernelGGL(k_s_reduce, dim3(B), dim3(kThreads), 0, st, sw.partial, p_stride, A.fout, A.noise,
                          eval_id, A.amp_rank == 0 ? 1 : 0);
     }
     SW_TRY(hipGetLastError());

@@ -143,8 +143,11 @@ struct TileBasis {
 
 // ops of every stream -> passes + tile coordinates.  passes: [batch][max_pass]; opc: [batch][max_ops]
 static_assert(sizeof(ChunkRec) == 96 && kTileK <= 3, "ChunkRec: three slots, 24 dwords");
+// gxp (or nullptr): the physical X masks of the Hamiltonian's groups, [batch][n_groups] - the LAST pass of a stream
+// takes as many of them into its basis as it has room for (instead of filler unit vectors): those groups are then
+// evaluated by k_t_ops while the final state is still in LDS (k_t_plan_energy makes that basis its pass 0).
 __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, TilePass* passes, OpCoord* opc,
-                             ChunkRec* chunks, int32_t* npass, int max_pass) {
+                             ChunkRec* chunks, int32_t* npass, int max_pass, const uint32_t* gxp) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= A.batch) return;
   const int nops = meta[(size_t)b * 8];
@@ -234,7 +237,14 @@ __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, Ti
   TileBasis B;
   B.reset();
   int begin = 0, np = 0;
-  auto close = [&](int end) {
+  auto close = [&](int end, bool last = false) {
+    if (last && gxp) {
+      const uint32_t* gx = gxp + (size_t)b * A.ham.n_groups;
+      for (int g = 0; g < A.ham.n_groups && B.dim < kTileBits; ++g) {
+        const uint32_t r = B.reduce(gx[g]);
+        if (r) B.add(r);
+      }
+    }
     B.fill(A.n);
     B.sort();
     if (np < max_pass) {
@@ -259,7 +269,7 @@ __global__ void k_t_plan_ops(BatchArgs A, const Op* ops, const int32_t* meta, Ti
     B.reset();
     B.add(B.reduce(op[o].xm));
   }
-  close(nops);                                           // (a stream without ops still gets its copy pass)
+  close(nops, true);                                     // (a stream without ops still gets its copy pass)
   npass[b] = np < max_pass ? np : max_pass;
 }
 
@@ -284,7 +294,9 @@ struct ETermRec {             // 4 + 2 kEPairs dwords
 };
 __global__ void k_t_plan_energy(BatchArgs A, int n_terms, const uint32_t* gxp, const uint32_t* tzp, const double* tsg,
                                 ETilePass* passes, int32_t* npass, int32_t* order, uint32_t* gcx, int32_t* grec,
-                                TermRec* trec, int32_t* gpass, EGroupRec* egrp, ETermRec* eterm, double* ewi) {
+                                TermRec* trec, int32_t* gpass, EGroupRec* egrp, ETermRec* eterm, double* ewi,
+                                const TilePass* opasses, const int32_t* onpass, int max_pass) {
+  static_assert(kETileBits == kTileBits, "the fused pass shares its tile with the last circuit pass");
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= A.batch) return;
   const int ng = A.ham.n_groups;
@@ -309,10 +321,20 @@ __global__ void k_t_plan_energy(BatchArgs A, int n_terms, const uint32_t* gxp, c
     dims[np] = kETileLow;
     return np++;
   };
+  const bool fused = opasses != nullptr;
+  if (fused) {      // pass 0 = the tile of the stream's last circuit pass (complete: takes the PAIR groups that lie in it, no more;
+                    // the diagonal group - the heaviest - stays with k_t_energy, where the sweeps overlap its arithmetic)
+    const TilePass& L = opasses[(size_t)b * max_pass + (onpass[b] > 0 ? onpass[b] - 1 : 0)];
+    int i = 0;
+    for (int q = 0; q < 32 && i < kETileBits; ++q)
+      if ((L.pivmask >> q) & 1u) { P[0].basis[i] = L.basis[i]; piv[0][i] = q; ++i; }
+    dims[0] = kETileBits;
+    np = 1;
+  }
   for (int g = 0; g < ng; ++g) {
     const uint32_t x = gx[g];
     int dst = -1;
-    for (int k = 0; k < np && dst < 0; ++k) {
+    for (int k = (fused && x == 0u) ? 1 : 0; k < np && dst < 0; ++k) {
       const uint32_t r = reduce(k, x);
       if (!r) dst = k;
       else if (dims[k] < kETileBits) { add(k, r); dst = k; }
@@ -426,221 +448,25 @@ __device__ __forceinline__ uint32_t tile_k_offset(const uint32_t (&basis)[BITS],
   return x;
 }
 
-// One pass of the circuit: stage the tile, apply the ops of the pass four at a time from registers, store.
-// Registers of a tile on its way between HBM and LDS.  A plain array that stays live around the tile loop is
-// left in scratch memory by the compiler (one scratch store per load, with a wait); members of a recursive
-// struct are scalars from the start.
-template <int N>
-struct TileRegs {
-  double2 v;
-  TileRegs<N - 1> rest;
-  template <class F> __device__ __forceinline__ void load(F f, int k = 0) { v = f(k); rest.load(f, k + 1); }
-  template <class F> __device__ __forceinline__ void store(F f, int k = 0) const { f(k, v); rest.store(f, k + 1); }
+// All X-mask groups of one energy pass on the tile that sits in LDS (tile coordinate t at tile[t]): used by k_t_energy
+// for every pass and by k_t_ops for the groups that close inside the LAST circuit pass of a stream (the fused pass:
+// the final state is evaluated before it leaves the LDS, one sweep over the state less).
+struct ETileArgs {
+  const EGroupRec* __restrict__ G;      // group records of the pass, in the order they run
+  const ETermRec* __restrict__ T;       // its term records
+  const double* __restrict__ WI;        // imaginary parts of the weights
+  int n_in_pass, r_count;
 };
-template <>
-struct TileRegs<0> {
-  template <class F> __device__ __forceinline__ void load(F, int = 0) {}
-  template <class F> __device__ __forceinline__ void store(F, int = 0) const {}
-};
-
-// (cos, sin) of every op's parameter in op order: k_t_ops reads them next to the chunk records, with no
-// dependent load through the parameter index
-__global__ void k_t_cs_ops(BatchArgs A, const Op* ops, const int32_t* meta, const double2* cs, double2* csop) {
-  const int b = blockIdx.y;
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= meta[(size_t)b * 8]) return;
-  const Op op = ops[(size_t)b * A.max_ops + o];
-  const int kd = op.kind & 0xff;
-  csop[(size_t)b * A.max_ops + o] =
-      (kd == OP_RX || kd == OP_RY || kd == OP_RZ) ? cs[(size_t)b * A.max_params + op.pidx] : make_double2(1.0, 0.0);
-}
-
-#ifndef VQE_OPS_TILES_PER_BLOCK
-#define VQE_OPS_TILES_PER_BLOCK 4
-#endif
-constexpr int kOpsTilesPerBlock = VQE_OPS_TILES_PER_BLOCK;
-// sign-flipped copy of s: bit 31 of `flipword` decides
-__device__ __forceinline__ double t_flip(double s, uint32_t flipword) {
-  return __hiloint2double(__double2hiint(s) ^ (int)(flipword & 0x80000000u), __double2loint(s));
-}
-// w[e] = c v[e] + s(e) v[e ^ F]: the per-element updates of s_apply_k (vqe_stream.h), same expressions
-template <int E, int F, bool RX>
-__device__ __forceinline__ void t_rot_pairs(double2 (&v)[E], double c, double s, uint32_t fw, uint32_t ebits) {
-  double2 w[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const double2 a = v[e], bq = v[e ^ F];
-    if (RX) w[e] = make_double2(c * a.x - s * bq.y, c * a.y + s * bq.x);
-    else {
-      const double sg = t_flip(s, fw ^ (ebits << (31 - e)));
-      w[e] = make_double2(c * a.x + sg * bq.x, c * a.y + sg * bq.y);
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < E; ++e) v[e] = w[e];
-}
-
-__global__ void __launch_bounds__(kThreads) k_t_ops(BatchArgs A, double2* states, const ChunkRec* __restrict__ chunks,
-                                                    const double2* __restrict__ csop, const TilePass* passes,
-                                                    const int32_t* npass, int pass, int max_pass, int tiles) {
-  constexpr int K = kTileK, E = 1 << K;
-  constexpr int NE = kTileAmps / kThreads;
-  static_assert(E == 8 && NE == 8, "k_t_ops: three ops per chunk, eight amplitudes per thread");
-  __shared__ double2 tile[kTileAmps];
-  const int b = blockIdx.y;
-  if (pass >= npass[b]) return;
-  const TilePass P = passes[(size_t)b * max_pass + pass];
-  uint32_t basis[kTileBits];
-#pragma unroll
-  for (int i = 0; i < kTileBits; ++i) basis[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.basis[i]);
-  const uint32_t pivmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.pivmask);
-  const size_t dim = (size_t)1 << A.n;
-  const uint32_t tid = threadIdx.x;
-  const uint32_t lane_off = tile_lane_offset<kTileLow>(basis, tid);
-  double2* psi = states + (size_t)b * dim;
-  const double2* src = pass == 0 ? A.init : psi;      // the first pass starts from the shared initial state
-  const int o_begin = __builtin_amdgcn_readfirstlane(P.begin), o_end = __builtin_amdgcn_readfirstlane(P.end);
-  const ChunkRec* __restrict__ CH = chunks + (size_t)b * A.max_ops;
-  const double2* __restrict__ CS = csop + (size_t)b * A.max_ops;
-  lds_cbyte* tile_rb = (lds_cbyte*)tile;
-  typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
-  lds_byte_t* tile_wb = (lds_byte_t*)tile;
-  // tiles blockIdx.x, blockIdx.x + gridDim.x, ... (see k_t_energy); the next one is in flight while this one is worked on
-  const int t_first = (int)blockIdx.x, t_step = (int)gridDim.x, t_last = tiles;
-  TileRegs<NE> stage;
-  uint32_t p0 = tile_origin((uint32_t)t_first, pivmask, A.n);
-  stage.load([&](int k) { return src[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
-  for (int tl = t_first; tl < t_last; tl += t_step) {
-    if (tl != t_first) __syncthreads();                 // the previous tile has left the LDS
-    stage.store([&](int k, const double2& v) { tile[tid + (uint32_t)k * kThreads] = v; });
-    __syncthreads();
-    const uint32_t pt = p0;
-    if (tl + t_step < t_last) {
-      p0 = tile_origin((uint32_t)(tl + t_step), pivmask, A.n);
-      stage.load([&](int k) { return src[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
-    }
-    for (int o = o_begin, cnt = 0; o < o_end; o += cnt) {
-      const ChunkRec& cr = CH[o];
-      const uint32_t pvc = cr.pvc;
-      cnt = (int)(pvc >> 16);
-      // the thread's coset: zeros inserted into tid at the pivot positions, then the 2^K combinations of the slot masks
-      uint32_t t0 = tid;
-#pragma unroll
-      for (int i = 0; i < K; ++i) t0 = insert0(t0, (int)((pvc >> (5 * i)) & 31u));
-      const uint32_t a0 = t0 << 4;
-      uint32_t off[E];
-      double2 v[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        uint32_t x = 0;
-#pragma unroll
-        for (int i = 0; i < K; ++i) if ((e >> i) & 1) x ^= cr.g16[i];
-        off[e] = a0 ^ x;
-        v[e] = lds_load_d2(tile_rb, off[e]);
-      }
-#pragma unroll 1
-      for (int j = 0; j < cnt; ++j) {
-        const uint32_t kfe = cr.op[j].kfe;
-        const int kind = (int)(kfe & 0xfu), flip = (int)((kfe >> 4) & 0xfu);
-        const uint32_t ebits = kfe >> 16;
-        const double2 c = CS[o + j];
-        // sign of element e: parity(t0 & cz) [vector] ^ ebits[e] ^ parity(tile origin & zm) ^ inversion [scalars]
-        const uint32_t fw = ((uint32_t)__builtin_popcount(t0 & cr.op[j].cz) +
-                             ((uint32_t)__builtin_popcount(pt & cr.op[j].zm) ^ ((kfe >> 8) & 1u))) << 31;
-        if (kind == OP_RX) {
-          switch (flip) {
-            case 1: t_rot_pairs<E, 1, true>(v, c.x, c.y, fw, ebits); break;
-            case 2: t_rot_pairs<E, 2, true>(v, c.x, c.y, fw, ebits); break;
-            case 3: t_rot_pairs<E, 3, true>(v, c.x, c.y, fw, ebits); break;
-            case 4: t_rot_pairs<E, 4, true>(v, c.x, c.y, fw, ebits); break;
-            case 5: t_rot_pairs<E, 5, true>(v, c.x, c.y, fw, ebits); break;
-            case 6: t_rot_pairs<E, 6, true>(v, c.x, c.y, fw, ebits); break;
-            default: t_rot_pairs<E, 7, true>(v, c.x, c.y, fw, ebits); break;
-          }
-        } else if (kind == OP_RY) {
-          switch (flip) {
-            case 1: t_rot_pairs<E, 1, false>(v, c.x, c.y, fw, ebits); break;
-            case 2: t_rot_pairs<E, 2, false>(v, c.x, c.y, fw, ebits); break;
-            case 3: t_rot_pairs<E, 3, false>(v, c.x, c.y, fw, ebits); break;
-            case 4: t_rot_pairs<E, 4, false>(v, c.x, c.y, fw, ebits); break;
-            case 5: t_rot_pairs<E, 5, false>(v, c.x, c.y, fw, ebits); break;
-            case 6: t_rot_pairs<E, 6, false>(v, c.x, c.y, fw, ebits); break;
-            default: t_rot_pairs<E, 7, false>(v, c.x, c.y, fw, ebits); break;
-          }
-        } else if (kind == OP_RZ) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const double sg = t_flip(c.y, fw ^ (ebits << (31 - e)));
-            const double2 a = v[e];
-            v[e] = make_double2(c.x * a.x - sg * a.y, c.x * a.y + sg * a.x);
-          }
-        } else if (kind == OP_PZ) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const uint32_t f = fw ^ (ebits << (31 - e));
-            v[e] = make_double2(t_flip(v[e].x, f), t_flip(v[e].y, f));
-          }
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        d2v_t q; q.x = v[e].x; q.y = v[e].y;
-        *(__attribute__((address_space(3))) d2v_t*)(tile_wb + off[e]) = q;
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int k = 0; k < NE; ++k) psi[(pt ^ lane_off) ^ tile_k_offset(basis, k)] = tile[tid + (uint32_t)k * kThreads];
-  }
-}
-
-// <psi|H_shard|psi>: every pass stages each tile once (read only) and evaluates all its X-mask groups from LDS.
-// grid = (tiles of this rank's amplitude slice, batch, passes); partial: [batch][passes][tiles].
-// Dynamic LDS: the tile (64 KiB) + the term records of the pass with the sign of the tile origin folded in
-// (per-term scalars fetched from global memory inside the group loops cost one L2 round trip per term).
-#ifndef VQE_TILES_PER_BLOCK
-#define VQE_TILES_PER_BLOCK 4
-#endif
-constexpr int kTilesPerBlock = VQE_TILES_PER_BLOCK;   // tiles a workgroup of k_t_energy walks through (the next one in flight while it computes)
-__global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double2* states, int n_terms, const ETilePass* passes,
-                                                       const int32_t* npass, const EGroupRec* __restrict__ egrp,
-                                                       const ETermRec* __restrict__ eterm, const double* __restrict__ ewi,
-                                                       double* partial, int tiles_rank) {
-  __shared__ double2 tile[kETileAmps];
-  double* red = (double*)tile;      // reused for the block reduction after the last read of the tile
-  const int b = blockIdx.y, pass = blockIdx.z;
-  const size_t slot = ((size_t)b * gridDim.z + pass) * gridDim.x + blockIdx.x;
-  if (pass >= npass[b]) {
-    if (threadIdx.x == 0) partial[slot] = 0.0;
-    return;
-  }
-  const ETilePass P = passes[(size_t)b * kMaxEnergyPasses + pass];
-  uint32_t basis[kETileBits];
-#pragma unroll
-  for (int i = 0; i < kETileBits; ++i) basis[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.basis[i]);
-  const uint32_t pivmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.pivmask);
-  const size_t dim = (size_t)1 << A.n;
-  const uint32_t tid = threadIdx.x;
-  const uint32_t lane_off = tile_lane_offset<kETileLow>(basis, tid);
-  const double2* psi = states + (size_t)b * dim;
+constexpr int kEBlobTerms = kEPairs <= 4 ? 2 : 1;   // term records requested one group ahead (scalar registers: 102 in all)
+__device__ __forceinline__ void e_tile_groups(const double2* tile, uint32_t tid, uint32_t pt, const ETileArgs& C, double& acc) {
   constexpr int NE = kETileAmps / kThreads;           // elements per thread
   constexpr int NPR = kEPairs;      // pairs per thread
-  constexpr int kBlobTerms = NPR <= 4 ? 2 : 1;   // term records requested one group ahead (scalar registers: 102 in all)
-  // this workgroup's tiles: blockIdx.x, blockIdx.x + gridDim.x, ... of this rank's slice.  Neighbouring tiles
-  // share their DRAM pages (a tile is 128 runs of 256 B spread over the state): workgroups that run side by side
-  // take neighbouring tiles, as a one-tile-per-workgroup grid does
-  const int t_first = (int)blockIdx.x, t_step = (int)gridDim.x, t_last = tiles_rank;
-  TileRegs<NE> stage;                                 // the next tile, on its way from HBM
-  uint32_t p0 = tile_origin((uint32_t)t_first + (uint32_t)A.amp_rank * (uint32_t)tiles_rank, pivmask, A.n);
-  stage.load([&](int k) { return psi[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
-  const int g_begin = __builtin_amdgcn_readfirstlane(P.begin), g_end = __builtin_amdgcn_readfirstlane(P.end);
-  const int r_begin = __builtin_amdgcn_readfirstlane(P.rec_begin), r_count = __builtin_amdgcn_readfirstlane(P.rec_count);
-  const EGroupRec* __restrict__ G = egrp + (size_t)b * A.ham.n_groups + g_begin;
-  const ETermRec* __restrict__ T = eterm + (size_t)b * n_terms + r_begin;
-  const double* __restrict__ WI = ewi + (size_t)b * n_terms + r_begin;
-  const int n_in_pass = g_end - g_begin;
+  constexpr int kBlobTerms = kEBlobTerms;
+  const EGroupRec* __restrict__ G = C.G;
+  const ETermRec* __restrict__ T = C.T;
+  const double* __restrict__ WI = C.WI;
+  const int n_in_pass = C.n_in_pass, r_count = C.r_count;
   lds_cbyte* tile_b = (lds_cbyte*)tile;
-  double acc = 0.0;
   // One group: its record and its first two term records are in scalar registers already (requested one group
   // ahead: a scalar load that misses its cache takes ~600 cycles, as long as the whole group)
   struct Blob { EGroupRec g; ETermRec t[kBlobTerms]; };
@@ -649,15 +475,7 @@ __global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double
 #pragma unroll
     for (int i = 0; i < kBlobTerms; ++i) B.t[i] = T[cur + i < r_count ? cur + i : 0];
   };
-  for (int tl = t_first; tl < t_last; tl += t_step) {
-    if (tl != t_first) __syncthreads();                 // the previous tile has been read to the end
-    stage.store([&](int k, const double2& v) { tile[tid + (uint32_t)k * kThreads] = v; });
-    __syncthreads();
-    const uint32_t pt = p0;                             // origin of the tile being evaluated
-    if (tl + t_step < t_last) {                         // request the next tile: it lands while this one is evaluated
-      p0 = tile_origin((uint32_t)(tl + t_step) + (uint32_t)A.amp_rank * (uint32_t)tiles_rank, pivmask, A.n);
-      stage.load([&](int k) { return psi[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
-    }
+  {
     // Sign sums D_k = sum_terms w (-1)^{parity(t_k & cz)}: the elements of a thread are t_k = t_0 ^ U_k with
     // U_k the same for every thread, so parity(t_k & cz) = parity(t_0 & cz) ^ parity(U_k & cz): one vector
     // parity per term, the k-dependence is the record's +-1 (a scalar operand of the FMA); the sign of the
@@ -766,6 +584,270 @@ __global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double
         body(B1, c1);
       }
     }
+    }
+}
+
+// One pass of the circuit: stage the tile, apply the ops of the pass four at a time from registers, store.
+// Registers of a tile on its way between HBM and LDS.  A plain array that stays live around the tile loop is
+// left in scratch memory by the compiler (one scratch store per load, with a wait); members of a recursive
+// struct are scalars from the start.
+template <int N>
+struct TileRegs {
+  double2 v;
+  TileRegs<N - 1> rest;
+  template <class F> __device__ __forceinline__ void load(F f, int k = 0) { v = f(k); rest.load(f, k + 1); }
+  template <class F> __device__ __forceinline__ void store(F f, int k = 0) const { f(k, v); rest.store(f, k + 1); }
+};
+template <>
+struct TileRegs<0> {
+  template <class F> __device__ __forceinline__ void load(F, int = 0) {}
+  template <class F> __device__ __forceinline__ void store(F, int = 0) const {}
+};
+
+// (cos, sin) of every op's parameter in op order: k_t_ops reads them next to the chunk records, with no
+// dependent load through the parameter index
+__global__ void k_t_cs_ops(BatchArgs A, const Op* ops, const int32_t* meta, const double2* cs, double2* csop) {
+  const int b = blockIdx.y;
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= meta[(size_t)b * 8]) return;
+  const Op op = ops[(size_t)b * A.max_ops + o];
+  const int kd = op.kind & 0xff;
+  csop[(size_t)b * A.max_ops + o] =
+      (kd == OP_RX || kd == OP_RY || kd == OP_RZ) ? cs[(size_t)b * A.max_params + op.pidx] : make_double2(1.0, 0.0);
+}
+
+#ifndef VQE_OPS_TILES_PER_BLOCK
+#define VQE_OPS_TILES_PER_BLOCK 4
+#endif
+constexpr int kOpsTilesPerBlock = VQE_OPS_TILES_PER_BLOCK;
+// sign-flipped copy of s: bit 31 of `flipword` decides
+__device__ __forceinline__ double t_flip(double s, uint32_t flipword) {
+  return __hiloint2double(__double2hiint(s) ^ (int)(flipword & 0x80000000u), __double2loint(s));
+}
+// w[e] = c v[e] + s(e) v[e ^ F]: the per-element updates of s_apply_k (vqe_stream.h), same expressions
+template <int E, int F, bool RX>
+__device__ __forceinline__ void t_rot_pairs(double2 (&v)[E], double c, double s, uint32_t fw, uint32_t ebits) {
+  double2 w[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const double2 a = v[e], bq = v[e ^ F];
+    if (RX) w[e] = make_double2(c * a.x - s * bq.y, c * a.y + s * bq.x);
+    else {
+      const double sg = t_flip(s, fw ^ (ebits << (31 - e)));
+      w[e] = make_double2(c * a.x + sg * bq.x, c * a.y + sg * bq.y);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = w[e];
+}
+
+// Fused pass (F.partial != nullptr): in the LAST pass of a stream the groups of energy pass 0 (whose tile this is,
+// k_t_plan_energy) are evaluated on every tile of this rank's slice before the tile is stored; one partial per
+// workgroup in F.partial[b * F.stride + F.offset + blockIdx.x].  FUSED: the instantiation that runs those last passes
+// (the other one then leaves them alone): the reduction's registers would cost every circuit pass a workgroup per CU.
+struct FusedEnergy {
+  double* partial;
+  const ETilePass* epasses;
+  const EGroupRec* egrp;
+  const ETermRec* eterm;
+  const double* ewi;
+  int n_terms, tiles_rank, stride, offset;
+};
+template <bool FUSED>
+__global__ void __launch_bounds__(kThreads, FUSED ? 4 : 1) k_t_ops(BatchArgs A, double2* states, const ChunkRec* __restrict__ chunks,
+                                                    const double2* __restrict__ csop, const TilePass* passes,
+                                                    const int32_t* npass, int pass, int max_pass, int tiles, FusedEnergy F) {
+  constexpr int K = kTileK, E = 1 << K;
+  constexpr int NE = kTileAmps / kThreads;
+  static_assert(E == 8 && NE == 8, "k_t_ops: three ops per chunk, eight amplitudes per thread");
+  __shared__ double2 tile[kTileAmps];
+  const int b = blockIdx.y;
+  if (pass >= npass[b]) return;
+  const TilePass P = passes[(size_t)b * max_pass + pass];
+  uint32_t basis[kTileBits];
+#pragma unroll
+  for (int i = 0; i < kTileBits; ++i) basis[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.basis[i]);
+  const uint32_t pivmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.pivmask);
+  const size_t dim = (size_t)1 << A.n;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane_off = tile_lane_offset<kTileLow>(basis, tid);
+  double2* psi = states + (size_t)b * dim;
+  const double2* src = pass == 0 ? A.init : psi;      // the first pass starts from the shared initial state
+  const int o_begin = __builtin_amdgcn_readfirstlane(P.begin), o_end = __builtin_amdgcn_readfirstlane(P.end);
+  const ChunkRec* __restrict__ CH = chunks + (size_t)b * A.max_ops;
+  const double2* __restrict__ CS = csop + (size_t)b * A.max_ops;
+  lds_cbyte* tile_rb = (lds_cbyte*)tile;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+  lds_byte_t* tile_wb = (lds_byte_t*)tile;
+  // tiles blockIdx.x, blockIdx.x + gridDim.x, ... (see k_t_energy); the next one is in flight while this one is worked on
+  const int t_first = (int)blockIdx.x, t_step = (int)gridDim.x, t_last = tiles;
+  // (F.partial set: the streams in their last pass belong to the FUSED instantiation, the others to the plain one)
+  if (F.partial != nullptr && (pass == npass[b] - 1) != FUSED) return;
+  constexpr bool fused = FUSED;
+  ETileArgs EA{nullptr, nullptr, nullptr, 0, 0};
+  int slice_lo = 0, slice_hi = 0;
+  if (fused) {
+    const ETilePass& EP = F.epasses[(size_t)b * kMaxEnergyPasses];
+    const int g_begin = __builtin_amdgcn_readfirstlane(EP.begin), g_end = __builtin_amdgcn_readfirstlane(EP.end);
+    const int r_begin = __builtin_amdgcn_readfirstlane(EP.rec_begin);
+    EA.G = F.egrp + (size_t)b * A.ham.n_groups + g_begin;
+    EA.T = F.eterm + (size_t)b * F.n_terms + r_begin;
+    EA.WI = F.ewi + (size_t)b * F.n_terms + r_begin;
+    EA.n_in_pass = g_end - g_begin;
+    EA.r_count = __builtin_amdgcn_readfirstlane(EP.rec_count);
+    slice_lo = A.amp_rank * F.tiles_rank;
+    slice_hi = slice_lo + F.tiles_rank;
+  }
+  double acc = 0.0;
+  TileRegs<NE> stage;
+  uint32_t p0 = tile_origin((uint32_t)t_first, pivmask, A.n);
+  stage.load([&](int k) { return src[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
+  for (int tl = t_first; tl < t_last; tl += t_step) {
+    if (tl != t_first) __syncthreads();                 // the previous tile has left the LDS
+    stage.store([&](int k, const double2& v) { tile[tid + (uint32_t)k * kThreads] = v; });
+    __syncthreads();
+    const uint32_t pt = p0;
+    if (tl + t_step < t_last) {
+      p0 = tile_origin((uint32_t)(tl + t_step), pivmask, A.n);
+      stage.load([&](int k) { return src[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
+    }
+    for (int o = o_begin, cnt = 0; o < o_end; o += cnt) {
+      const ChunkRec& cr = CH[o];
+      const uint32_t pvc = cr.pvc;
+      cnt = (int)(pvc >> 16);
+      // the thread's coset: zeros inserted into tid at the pivot positions, then the 2^K combinations of the slot masks
+      uint32_t t0 = tid;
+#pragma unroll
+      for (int i = 0; i < K; ++i) t0 = insert0(t0, (int)((pvc >> (5 * i)) & 31u));
+      const uint32_t a0 = t0 << 4;
+      uint32_t off[E];
+      double2 v[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) if ((e >> i) & 1) x ^= cr.g16[i];
+        off[e] = a0 ^ x;
+        v[e] = lds_load_d2(tile_rb, off[e]);
+      }
+#pragma unroll 1
+      for (int j = 0; j < cnt; ++j) {
+        const uint32_t kfe = cr.op[j].kfe;
+        const int kind = (int)(kfe & 0xfu), flip = (int)((kfe >> 4) & 0xfu);
+        const uint32_t ebits = kfe >> 16;
+        const double2 c = CS[o + j];
+        // sign of element e: parity(t0 & cz) [vector] ^ ebits[e] ^ parity(tile origin & zm) ^ inversion [scalars]
+        const uint32_t fw = ((uint32_t)__builtin_popcount(t0 & cr.op[j].cz) +
+                             ((uint32_t)__builtin_popcount(pt & cr.op[j].zm) ^ ((kfe >> 8) & 1u))) << 31;
+        if (kind == OP_RX) {
+          switch (flip) {
+            case 1: t_rot_pairs<E, 1, true>(v, c.x, c.y, fw, ebits); break;
+            case 2: t_rot_pairs<E, 2, true>(v, c.x, c.y, fw, ebits); break;
+            case 3: t_rot_pairs<E, 3, true>(v, c.x, c.y, fw, ebits); break;
+            case 4: t_rot_pairs<E, 4, true>(v, c.x, c.y, fw, ebits); break;
+            case 5: t_rot_pairs<E, 5, true>(v, c.x, c.y, fw, ebits); break;
+            case 6: t_rot_pairs<E, 6, true>(v, c.x, c.y, fw, ebits); break;
+            default: t_rot_pairs<E, 7, true>(v, c.x, c.y, fw, ebits); break;
+          }
+        } else if (kind == OP_RY) {
+          switch (flip) {
+            case 1: t_rot_pairs<E, 1, false>(v, c.x, c.y, fw, ebits); break;
+            case 2: t_rot_pairs<E, 2, false>(v, c.x, c.y, fw, ebits); break;
+            case 3: t_rot_pairs<E, 3, false>(v, c.x, c.y, fw, ebits); break;
+            case 4: t_rot_pairs<E, 4, false>(v, c.x, c.y, fw, ebits); break;
+            case 5: t_rot_pairs<E, 5, false>(v, c.x, c.y, fw, ebits); break;
+            case 6: t_rot_pairs<E, 6, false>(v, c.x, c.y, fw, ebits); break;
+            default: t_rot_pairs<E, 7, false>(v, c.x, c.y, fw, ebits); break;
+          }
+        } else if (kind == OP_RZ) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const double sg = t_flip(c.y, fw ^ (ebits << (31 - e)));
+            const double2 a = v[e];
+            v[e] = make_double2(c.x * a.x - sg * a.y, c.x * a.y + sg * a.x);
+          }
+        } else if (kind == OP_PZ) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const uint32_t f = fw ^ (ebits << (31 - e));
+            v[e] = make_double2(t_flip(v[e].x, f), t_flip(v[e].y, f));
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        d2v_t q; q.x = v[e].x; q.y = v[e].y;
+        *(__attribute__((address_space(3))) d2v_t*)(tile_wb + off[e]) = q;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) psi[(pt ^ lane_off) ^ tile_k_offset(basis, k)] = tile[tid + (uint32_t)k * kThreads];
+    // the final state of this tile, evaluated while the stores above drain (the tile is complete: the last chunk
+    // ended with a barrier, a pass without ops staged it behind one)
+    if (fused && tl >= slice_lo && tl < slice_hi) e_tile_groups(tile, tid, pt, EA, acc);
+  }
+  if (fused) {
+    __syncthreads();            // all reads of the tile are done: its first words become the reduction scratch
+    const double tot = block_sum(acc, (double*)tile);
+    if (threadIdx.x == 0) F.partial[(size_t)b * F.stride + F.offset + blockIdx.x] = tot;
+  }
+}
+
+// <psi|H_shard|psi>: every pass stages each tile once (read only) and evaluates all its X-mask groups from LDS.
+// grid = (tiles of this rank's amplitude slice, batch, passes); partial: [batch][passes][tiles].
+// Dynamic LDS: the tile (64 KiB) + the term records of the pass with the sign of the tile origin folded in
+// (per-term scalars fetched from global memory inside the group loops cost one L2 round trip per term).
+#ifndef VQE_TILES_PER_BLOCK
+#define VQE_TILES_PER_BLOCK 4
+#endif
+constexpr int kTilesPerBlock = VQE_TILES_PER_BLOCK;   // tiles a workgroup of k_t_energy walks through (the next one in flight while it computes)
+__global__ void __launch_bounds__(kThreads) k_t_energy(BatchArgs A, const double2* states, int n_terms, const ETilePass* passes,
+                                                       const int32_t* npass, const EGroupRec* __restrict__ egrp,
+                                                       const ETermRec* __restrict__ eterm, const double* __restrict__ ewi,
+                                                       double* partial, int tiles_rank, int stride, int skip0) {
+  __shared__ double2 tile[kETileAmps];
+  double* red = (double*)tile;      // reused for the block reduction after the last read of the tile
+  const int b = blockIdx.y, pass = blockIdx.z;
+  const size_t slot = (size_t)b * stride + (size_t)pass * gridDim.x + blockIdx.x;
+  if (pass >= npass[b] || (skip0 && pass == 0)) {      // (skip0: pass 0 was evaluated by the last circuit pass)
+    if (threadIdx.x == 0) partial[slot] = 0.0;
+    return;
+  }
+  const ETilePass P = passes[(size_t)b * kMaxEnergyPasses + pass];
+  uint32_t basis[kETileBits];
+#pragma unroll
+  for (int i = 0; i < kETileBits; ++i) basis[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.basis[i]);
+  const uint32_t pivmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.pivmask);
+  const size_t dim = (size_t)1 << A.n;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane_off = tile_lane_offset<kETileLow>(basis, tid);
+  const double2* psi = states + (size_t)b * dim;
+  constexpr int NE = kETileAmps / kThreads;           // elements per thread
+  // this workgroup's tiles: blockIdx.x, blockIdx.x + gridDim.x, ... of this rank's slice.  Neighbouring tiles
+  // share their DRAM pages (a tile is 128 runs of 256 B spread over the state): workgroups that run side by side
+  // take neighbouring tiles, as a one-tile-per-workgroup grid does
+  const int t_first = (int)blockIdx.x, t_step = (int)gridDim.x, t_last = tiles_rank;
+  TileRegs<NE> stage;                                 // the next tile, on its way from HBM
+  uint32_t p0 = tile_origin((uint32_t)t_first + (uint32_t)A.amp_rank * (uint32_t)tiles_rank, pivmask, A.n);
+  stage.load([&](int k) { return psi[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
+  const int g_begin = __builtin_amdgcn_readfirstlane(P.begin), g_end = __builtin_amdgcn_readfirstlane(P.end);
+  const int r_begin = __builtin_amdgcn_readfirstlane(P.rec_begin), r_count = __builtin_amdgcn_readfirstlane(P.rec_count);
+  const EGroupRec* __restrict__ G = egrp + (size_t)b * A.ham.n_groups + g_begin;
+  const ETermRec* __restrict__ T = eterm + (size_t)b * n_terms + r_begin;
+  const double* __restrict__ WI = ewi + (size_t)b * n_terms + r_begin;
+  const int n_in_pass = g_end - g_begin;
+  double acc = 0.0;
+  for (int tl = t_first; tl < t_last; tl += t_step) {
+    if (tl != t_first) __syncthreads();                 // the previous tile has been read to the end
+    stage.store([&](int k, const double2& v) { tile[tid + (uint32_t)k * kThreads] = v; });
+    __syncthreads();
+    const uint32_t pt = p0;                             // origin of the tile being evaluated
+    if (tl + t_step < t_last) {                         // request the next tile: it lands while this one is evaluated
+      p0 = tile_origin((uint32_t)(tl + t_step) + (uint32_t)A.amp_rank * (uint32_t)tiles_rank, pivmask, A.n);
+      stage.load([&](int k) { return psi[(p0 ^ lane_off) ^ tile_k_offset(basis, k)]; });
+    }
+    e_tile_groups(tile, tid, pt, ETileArgs{G, T, WI, n_in_pass, r_count}, acc);
   }
   __syncthreads();            // all reads of the tile are done: its first words become the reduction scratch
   const double tot = block_sum(acc, red);
