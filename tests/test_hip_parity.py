@@ -742,7 +742,14 @@ def test_engine_plumbing(tq):
             eng.batch_run_reduction()            # states resident: the Pauli reduction alone
             eng.batch_copy_energy(buf.data_ptr())
             eng.sync()
-            assert np.array_equal(buf.cpu().numpy(), f)
+            # (not the same bits: the full evaluation sums the pair groups of its last circuit pass's tile in that pass -
+            # the fused pass, DESIGN 4.3 - the reduction alone plans three sweeps of its own; each is reproducible)
+            assert np.abs(buf.cpu().numpy() - f).max() < 1e-12
+            first = buf.cpu().numpy().copy()
+            eng.batch_run_reduction()
+            eng.batch_copy_energy(buf.data_ptr())
+            eng.sync()
+            assert np.array_equal(buf.cpu().numpy(), first)
         else:
             with pytest.raises(tq.VQEError):
                 eng.batch_run_reduction()
