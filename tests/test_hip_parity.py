@@ -488,6 +488,41 @@ def test_noise_trajectories_match_oracle(tq):
     assert np.abs(eng.get_state(th) - vo.run_circuit(psi0, kind, q0, q1, pidx, th, dr)).max() < A_TOL
 
 
+def test_noise_trajectories_on_the_streaming_path(tq):
+    """The same check at 14 qubits: the tile planners run anew for every evaluation (the drawn Paulis change the sign
+    masks and, through X errors, the layout), the pair groups of the last circuit pass's tile are evaluated in that pass
+    (fused pass) - with the oracle's draws the energies agree to 1e-10, for a Hamiltonian with hopping pairs (half
+    groups) and one without."""
+    import c_oracle as co
+    n = 14
+    rng = np.random.default_rng(1421)
+    psi0 = random_state(n, rng)
+    base = random_gates(n, 14, rng)
+    kind, q0, q1, pidx = [], [], [], []
+    for k, a, b, p in zip(*base[:4]):
+        kind.append(k), q0.append(a), q1.append(b), pidx.append(p)
+        kind.append(5 if k == 0 else 4), q0.append(a), q1.append(b if k == 0 else -1), pidx.append(-1)
+    kind, q0, q1, pidx = (np.array(v, np.int32) for v in (kind, q0, q1, pidx))
+    th = base[4]
+    p1, p2, seed = 0.25, 0.5, 424242
+    hh, _ = tq.hamiltonian.heisenberg(n)
+    for ham in ((hh.xmask, hh.zmask, hh.coeff), random_hamiltonian(n, 30, rng)):
+        eng = _engine(tq, n, psi0, ham)
+        eng.set_noise(p1, p2, seed)
+        eng.set_circuit(tq.Circuit(kind, q0, q1, pidx, th.size))
+        for e in range(4):
+            got = eng.energy(th)
+            dr = co.noise_draws(seed, 0, e, kind, p1, p2)
+            ref = vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th, dr), *ham)
+            assert abs(got - ref) < E_TOL, (e, got, ref)
+        got = eng.energy_batch(np.tile(th, (3, 1)))
+        for b in range(3):
+            dr = co.noise_draws(seed, b, 4, kind, p1, p2)
+            ref = vo.energy_pauli(vo.run_circuit(psi0, kind, q0, q1, pidx, th, dr), *ham)
+            assert abs(got[b] - ref) < E_TOL
+        eng.close()
+
+
 @pytest.mark.parametrize("n,G,seed", [(9, 40, 0), (10, 60, 1), (11, 90, 2), (13, 70, 3), (10, 170, 4), (12, 150, 5)])
 def test_register_path_sizes(tq, n, G, seed):
     """n = 10..13 run with the amplitudes in registers (coset layouts), n = 9 is the largest
