@@ -6,10 +6,10 @@
 // 31.5 k evaluations/s on the 20-qubit bench workload against 25.9 k with 64 KiB tiles and 28.4 k with
 // 16 KiB ones - occupancy against passes) and does everything that closes inside it before the tile goes back:
 //   * a tile is a coset p0 ^ V of an 11-dimensional subspace V of GF(2)^n that contains the unit vectors
-//     e_0..e_3 (so the tile is made of aligned 256-byte runs: coalesced loads and stores) plus up to
-//     seven independent pair masks - the physical partner masks A^-1 e_q of the rotations (vqe_device.h:
-//     CNOTs never move data), or the physical X masks of Pauli groups; masks that DEPEND on the basis ride
-//     along for free;
+//     e_0..e_2 (circuit passes: aligned 128-byte runs, coalesced loads and stores) resp. e_0..e_3 (the reduction:
+//     256-byte runs) plus up to eight resp. seven independent pair masks - the physical partner masks A^-1 e_q of
+//     the rotations (vqe_device.h: CNOTs never move data), or the physical X masks of Pauli groups; masks that
+//     DEPEND on the basis ride along for free;
 //   * a planner thread per stream cuts the op list into passes (maximal runs of ops whose masks fit one
 //     V) and packs the X-mask groups into passes first-fit; V is kept as a fully reduced basis, so tile
 //     coordinates of a mask are just its bits at the pivot positions, and the sign selector parity(p & z)
@@ -19,7 +19,10 @@
 //     (the coset trick of k_s_opk, in tile coordinates: 256 threads x 8 amplitudes), so LDS sees one read + one
 //     write of the tile per chunk;
 //   * the first pass of a stream reads the shared initial state instead of its own buffer (no separate
-//     initialisation sweep);
+//     initialisation sweep); the LAST pass takes Pauli-group masks into its basis where it has room and evaluates
+//     the pair groups that close inside its tile before the tile is stored (the fused pass: one reduction sweep
+//     less for most streams); pair groups of two equal-magnitude real terms (XX + YY of a bond) are evaluated on the
+//     half space on which their sum does not vanish (half groups);
 //   * a workgroup walks several tiles with the next one already in flight, and everything a kernel needs per
 //     chunk / group / term comes precomputed from the planner by scalar loads: a SIMD issues one instruction per
 //     4-5 cycles whatever its kind, so the instruction count per amplitude is what these kernels are written for
