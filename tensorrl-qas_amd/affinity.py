@@ -26,16 +26,24 @@ def l3_domains(cpus=None):
 
 
 def bind_host_threads(local_rank=0, ranks_per_node=8):
-    """Confine the calling thread (and the threads it creates from now on) to one L3 domain; rank r of a node takes
-    domain r * (domains // ranks_per_node), so that the ranks of a node spread over its sockets the way its GPUs do.
+    """Confine the calling thread (and the threads it creates from now on) to one L3 domain: a single process takes the
+    domain it is running on; under a launcher (LOCAL_RANK set) rank r of a node takes domain r * (domains //
+    ranks_per_node), so that the ranks of a node spread over its sockets the way its GPUs do.
     Returns the CPU list, or None when nothing was done (switched off, one domain only, no sysfs)."""
     if os.environ.get("VQE_CPU_BIND", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
     doms = l3_domains()
     if len(doms) <= 1:
         return None
+    # start from the domain the scheduler put this thread on (on a shared host the first domain is everybody's first
+    # choice), ranks of one node a fixed stride apart
+    here = 0
+    if hasattr(os, "sched_getcpu"):
+        cpu = os.sched_getcpu()
+        here = next((i for i, d in enumerate(doms) if cpu in d), 0)
     stride = max(1, len(doms) // max(1, ranks_per_node))
-    cpus = doms[(local_rank * stride) % len(doms)]
+    first = here if ranks_per_node <= 1 or "LOCAL_RANK" not in os.environ else 0
+    cpus = doms[(first + local_rank * stride) % len(doms)]
     try:
         os.sched_setaffinity(0, cpus)
     except OSError:
